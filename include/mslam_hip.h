@@ -1,0 +1,171 @@
+/* mslam_hip.h — C ABI of the MI355X-native ORB / Hamming-match / BoW front end.
+ *
+ * This is the drop-in boundary for modular-slam's feature hot path.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repo,
+ * src/lib/modular_slam/...).  Plain C types only; no exceptions cross this boundary; every function
+ * returns an int status (0 = MSLAM_HIP_OK) and mslam_hip_last_error() gives the text.
+ *
+ * Threading: a context is NOT thread-safe (the reference detector is not re-entrant either — it owns
+ * its pyramid scratch, distributed_cv_feature.cpp:651).  Use one context per GPU / per caller thread.
+ * Host-pointer entry points are synchronous (they return after the D2H copy); *_dev entry points
+ * enqueue on the context's HIP stream and return without synchronising.
+ */
+#ifndef MSLAM_HIP_H_
+#define MSLAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSLAM_HIP_ABI_VERSION 1
+
+enum
+{
+    MSLAM_HIP_OK = 0,
+    MSLAM_HIP_E_INVALID = 1,  /* bad argument / unsupported size */
+    MSLAM_HIP_E_RUNTIME = 2,  /* HIP runtime failure (no device, launch failure, OOM...) */
+    MSLAM_HIP_E_CAPACITY = 3, /* an output or scratch capacity was exceeded; no partial result is valid */
+    MSLAM_HIP_E_NO_VOCABULARY = 4,
+    MSLAM_HIP_E_FORMAT = 5 /* vocabulary stream not understood */
+};
+
+typedef struct mslam_hip_ctx mslam_hip_ctx;
+
+/* Detector parameters.  Defaults are the reference's hard-coded operating point
+ * (distributed_cv_feature.cpp:1184-1186): orb_params("orb", 1.2f, 8, 20, 7), min node area 1000. */
+typedef struct
+{
+    int32_t width, height;  /* frame size every call on this context uses (reference: 640x480)            */
+    int32_t max_batch;      /* frames per batched device launch, >= 1                                      */
+    int32_t n_levels;       /* pyramid levels (8)                                                          */
+    float scale_factor;     /* pyramid scale (1.2f); level scales are the float32 chain of :411-420        */
+    int32_t ini_fast_thr;   /* first FAST threshold (20)                                                   */
+    int32_t min_fast_thr;   /* fallback threshold for cells that found nothing (7), :922-926               */
+    uint32_t min_node_area; /* quadtree stop area in level-0 px^2 (1000), :1002,:1186                      */
+    int32_t max_keypoints;  /* per-frame keypoint capacity of the output buffers                           */
+    int32_t max_candidates; /* per-(frame,level) FAST candidate capacity feeding the quadtree              */
+    int32_t device;         /* HIP device ordinal                                                          */
+    void* stream;           /* hipStream_t to enqueue on; NULL = the context creates its own               */
+} mslam_hip_params;
+
+void mslam_hip_default_params(mslam_hip_params* p);
+int mslam_hip_abi_version(void);
+
+int mslam_hip_create(const mslam_hip_params* p, mslam_hip_ctx** out);
+void mslam_hip_destroy(mslam_hip_ctx* ctx);
+/* ctx may be NULL: returns the message of the last failed mslam_hip_create on this thread. */
+const char* mslam_hip_last_error(const mslam_hip_ctx* ctx);
+/* Block until everything enqueued on the context's stream has finished; also surfaces capacity
+ * overflows recorded by *_dev launches (returns MSLAM_HIP_E_CAPACITY once, then clears). */
+int mslam_hip_sync(mslam_hip_ctx* ctx);
+
+/* ---- IFeatureDetector<RgbFrame,uint8_t,32>::detect ------------------------------------------------
+ * Replaces DistributedOrbOpenCvDetector::detect (distributed_cv_feature.cpp:1190-1222; interface
+ * frontend/feature/feature_interface.hpp:50-56).  `bgr` is the RgbFrame::data buffer: interleaved
+ * 3-channel u8, row-major, no padding (types/rgb_frame.hpp:12-16).  Outputs are SoA, caller
+ * allocated, `max_out` entries each: xy = scale-corrected float coordinates (x0,y0,x1,y1,...) in
+ * the reference's order (level 0..L-1, quadtree node-list order inside a level); desc = 32 bytes per
+ * keypoint; octave/angle/response may be NULL.  The reference's Keypoint::id is the output index. */
+int mslam_hip_detect(mslam_hip_ctx* ctx, const uint8_t* bgr, int width, int height, int max_out, float* xy,
+                     uint8_t* desc, int32_t* octave, float* angle, float* response, int* n_out);
+
+/* Device-resident batched form of the same operator: `d_bgr` holds n_frames (<= max_batch)
+ * back-to-back frames in HBM.  Results stay in context-owned device buffers (mslam_hip_batch_view). */
+int mslam_hip_detect_batch_dev(mslam_hip_ctx* ctx, const uint8_t* d_bgr, int n_frames);
+
+typedef struct
+{
+    int32_t n_frames;     /* frames in the last detect batch                                     */
+    int32_t capacity;     /* max_keypoints: per-frame stride (in keypoints) of the arrays below  */
+    const float* xy;      /* [max_batch][capacity][2]                                            */
+    const uint8_t* desc;  /* [max_batch][capacity][32]                                           */
+    const int32_t* octave;
+    const float* angle;
+    const float* response;
+    const int32_t* count; /* [max_batch] keypoints per frame                                     */
+    /* results of mslam_hip_match_batch_dev, frame t matched against frame t-1: */
+    const int32_t* match_from; /* [max_batch][capacity] index into frame t   (fromIndex)         */
+    const int32_t* match_to;   /* [max_batch][capacity] index into frame t-1 (toIndex)           */
+    const int32_t* match_count; /* [max_batch]; 0 for a frame without predecessor                */
+} mslam_hip_batch_view;
+int mslam_hip_get_batch_view(mslam_hip_ctx* ctx, mslam_hip_batch_view* view);
+
+/* ---- IFeatureMatcher<uint8_t,32>::match ------------------------------------------------------------
+ * Replaces OrbOpenCvMatcher::match(from, to) (orb_feature.cpp:84-117; interface
+ * feature_interface.hpp:62-70): BFMatcher(HAMMING).knnMatch(query = to, train = from, k = 2) and the
+ * ratio test (double)d0 < ratio*(double)d1 (:96-105, reference ratio 0.7).  Descriptors are packed
+ * 32-byte rows.  Outputs (capacity n_to each) are ordered by query (= to) index (:110-114).
+ * n_from < 2 is undefined behaviour in the reference (:101); here it yields zero matches. */
+int mslam_hip_match(mslam_hip_ctx* ctx, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,
+                    double ratio, int32_t* from_idx, int32_t* to_idx, int* n_out);
+/* The knnMatch(k=2) result itself, per query row of `to`: train indices (-1 if absent) and integer
+ * Hamming distances (INT32_MAX if absent), best first; ties rank the lower train index first. */
+int mslam_hip_match_knn2(mslam_hip_ctx* ctx, const uint8_t* from_desc, int n_from, const uint8_t* to_desc,
+                         int n_to, int32_t* idx0, int32_t* idx1, int32_t* dist0, int32_t* dist1);
+/* Batched device form: for every frame t of the last detect batch, match(from = frame t,
+ * to = frame t-1); frame 0 is matched against the last frame of the previous batch when
+ * `chain_previous` is non-zero and one exists.  Results: mslam_hip_batch_view.match_*. */
+int mslam_hip_match_batch_dev(mslam_hip_ctx* ctx, double ratio, int chain_previous);
+
+/* ---- IRelocalizer / ILoopDetector: DBoW3 bag of words ---------------------------------------------
+ * Replaces what OrbRelocalizer is wired for (orb_relocalizer.cpp:26-50, relocalizer.hpp:11-20,
+ * loop_detection.hpp:10-15): DBoW3::Vocabulary::transform and Database add/query with L1 scoring.
+ * `blob` is a DBoW3 binary vocabulary stream (Vocabulary::toStream/fromStream,
+ * conan_recipes/dbow3/dbow3.patch:2252-2355,2544-2651), uncompressed. */
+int mslam_hip_bow_load(mslam_hip_ctx* ctx, const void* blob, size_t size);
+int mslam_hip_bow_info(mslam_hip_ctx* ctx, int* k, int* L, int* n_nodes, int* n_words, int* scoring,
+                       int* weighting);
+/* Vocabulary::transform(feature, word_id, weight) for n descriptors (dbow3.patch:1760-1860). */
+int mslam_hip_bow_words(mslam_hip_ctx* ctx, const uint8_t* desc, int n, uint32_t* word, double* weight);
+/* Vocabulary::transform(features, BowVector) (dbow3.patch:1432-1530): ascending word ids, values
+ * normalised as the vocabulary's scoring requires.  Capacity of words/values: n. */
+int mslam_hip_bow_transform(mslam_hip_ctx* ctx, const uint8_t* desc, int n, uint32_t* words, double* values,
+                            int* n_words);
+/* DBoW3 L1Scoring::score of two BoW vectors, in [0,1]. */
+int mslam_hip_bow_score(mslam_hip_ctx* ctx, const uint32_t* w1, const double* v1, int n1, const uint32_t* w2,
+                        const double* v2, int n2, double* score);
+/* Database: add(features) -> entry id (IRelocalizer::addKeyframe's feed, rgbd_feature_frontend.cpp:176)
+ * and query(features) -> the best max_results entries by L1 score, best first, ties by lower entry
+ * id (IRelocalizer::relocalize / ILoopDetector::detectLoop). */
+int mslam_hip_bow_db_add(mslam_hip_ctx* ctx, const uint8_t* desc, int n, int* entry_id);
+int mslam_hip_bow_db_query(mslam_hip_ctx* ctx, const uint8_t* desc, int n, int max_results, int32_t* entry_ids,
+                           double* scores, int* n_results);
+int mslam_hip_bow_db_clear(mslam_hip_ctx* ctx);
+/* Batched device form: transform every frame of the last detect batch into a BoW vector, score it
+ * against the database (all entries), then add it as a new entry.  Per frame: best entry and score. */
+int mslam_hip_bow_batch_dev(mslam_hip_ctx* ctx, int add_to_db);
+typedef struct
+{
+    int32_t capacity;        /* per-frame stride of words/values                */
+    const uint32_t* words;   /* [max_batch][capacity]                           */
+    const double* values;    /* [max_batch][capacity]                           */
+    const int32_t* n_words;  /* [max_batch]                                     */
+    const int32_t* best_entry; /* [max_batch] (-1 if the database was empty)    */
+    const double* best_score;  /* [max_batch]                                   */
+} mslam_hip_bow_view;
+int mslam_hip_get_bow_view(mslam_hip_ctx* ctx, mslam_hip_bow_view* view);
+
+/* ---- test / debug access to intermediate stages (host copies; synchronises) -----------------------*/
+enum
+{
+    MSLAM_HIP_DBG_PYRAMID = 0,    /* u8 [h_l][w_l] unblurred level                               */
+    MSLAM_HIP_DBG_BLURRED = 1,    /* u8 [h_l][w_l] 7x7 sigma-2 blurred level                     */
+    MSLAM_HIP_DBG_CANDIDATES = 2, /* float triples (x, y, response), border-relative, FAST order */
+    MSLAM_HIP_DBG_SELECTED = 3    /* float triples after the quadtree, node-list order           */
+};
+int mslam_hip_level_geometry(mslam_hip_ctx* ctx, int* widths, int* heights, float* scales);
+int mslam_hip_debug_read(mslam_hip_ctx* ctx, int what, int frame, int level, void* dst, size_t dst_bytes,
+                         size_t* n_items);
+
+/* Per-stage device time (ms) of the last mslam_hip_detect_batch_dev / match_batch_dev when profiling
+ * is enabled (HIP events on the context's stream).  names/ms hold up to cap entries. */
+int mslam_hip_set_profiling(mslam_hip_ctx* ctx, int enable);
+int mslam_hip_get_stage_times(mslam_hip_ctx* ctx, const char** names, float* ms, int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSLAM_HIP_H_ */

@@ -1,0 +1,390 @@
+"""modular-slam_amd — MI355X-native ORB / Hamming-match / BoW front end for modular-slam.
+
+This package is the thin Python harness over the C ABI (include/mslam_hip.h) implemented by
+libmslam_hip.so (HIP kernels for gfx950, modular-slam_amd/csrc/).  It mirrors the reference's plugin
+interfaces for this path (feature_interface.hpp:50-70, relocalizer.hpp:11-20,
+loop_detection.hpp:10-15) with the same names and argument meaning:
+
+    HipOrbDetector.detect(rgb_frame)          ~ IFeatureDetector<RgbFrame,uint8_t,32>::detect
+    HipOrbMatcher.match(first, second)        ~ IFeatureMatcher<uint8_t,32>::match
+    HipOrbRelocalizer.addKeyframe/relocalize  ~ IRelocalizer<...>
+    HipLoopDetector.detectLoop()              ~ ILoopDetector<...>
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is present, calls
+raise.  (The directory name has a hyphen, so import it through `__graft_entry__.load_package()`,
+which registers it as module `modular_slam_amd`.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmslam_hip.so")
+
+OK, E_INVALID, E_RUNTIME, E_CAPACITY, E_NO_VOCABULARY, E_FORMAT = range(6)
+DBG_PYRAMID, DBG_BLURRED, DBG_CANDIDATES, DBG_SELECTED = range(4)
+
+# every symbol include/mslam_hip.h declares (tests/test_cabi_symbols.py checks the .so exports them all)
+ABI_SYMBOLS = [
+    "mslam_hip_default_params", "mslam_hip_abi_version", "mslam_hip_create", "mslam_hip_destroy",
+    "mslam_hip_last_error", "mslam_hip_sync", "mslam_hip_detect", "mslam_hip_detect_batch_dev",
+    "mslam_hip_get_batch_view", "mslam_hip_match", "mslam_hip_match_knn2", "mslam_hip_match_batch_dev",
+    "mslam_hip_bow_load", "mslam_hip_bow_info", "mslam_hip_bow_words", "mslam_hip_bow_transform",
+    "mslam_hip_bow_score", "mslam_hip_bow_db_add", "mslam_hip_bow_db_query", "mslam_hip_bow_db_clear",
+    "mslam_hip_bow_batch_dev", "mslam_hip_get_bow_view", "mslam_hip_level_geometry", "mslam_hip_debug_read",
+    "mslam_hip_set_profiling", "mslam_hip_get_stage_times",
+]
+
+
+class MslamHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mslam_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32), ("n_levels", C.c_int32),
+                ("scale_factor", C.c_float), ("ini_fast_thr", C.c_int32), ("min_fast_thr", C.c_int32),
+                ("min_node_area", C.c_uint32), ("max_keypoints", C.c_int32), ("max_candidates", C.c_int32),
+                ("device", C.c_int32), ("stream", C.c_void_p)]
+
+
+class BatchView(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("capacity", C.c_int32), ("xy", C.c_void_p), ("desc", C.c_void_p),
+                ("octave", C.c_void_p), ("angle", C.c_void_p), ("response", C.c_void_p), ("count", C.c_void_p),
+                ("match_from", C.c_void_p), ("match_to", C.c_void_p), ("match_count", C.c_void_p)]
+
+
+class BowView(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("words", C.c_void_p), ("values", C.c_void_p), ("n_words", C.c_void_p),
+                ("best_entry", C.c_void_p), ("best_score", C.c_void_p)]
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libmslam_hip.so (in-tree)."""
+    subprocess.check_call(["make", "-j8", "-C", _HERE] + ([] if verbose else ["-s"]))
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  Fails loudly when it has not been built — there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MslamHipError(E_RUNTIME, "libmslam_hip.so is not built (run __graft_entry__.build()); "
+                                           "the product path has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.mslam_hip_last_error.restype = C.c_char_p
+        L.mslam_hip_last_error.argtypes = [C.c_void_p]
+        L.mslam_hip_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.mslam_hip_destroy.argtypes = [C.c_void_p]
+        L.mslam_hip_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = Params()
+    lib().mslam_hip_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """Owner of one mslam_hip_ctx (one per GPU / caller thread)."""
+
+    def __init__(self, **kw):
+        self.params = default_params(**kw)
+        h = C.c_void_p()
+        rc = lib().mslam_hip_create(C.byref(self.params), C.byref(h))
+        if rc != OK:
+            raise MslamHipError(rc, (lib().mslam_hip_last_error(None) or b"").decode())
+        self._h = h
+        self.L = lib()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.mslam_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise MslamHipError(rc, (self.L.mslam_hip_last_error(self._h) or b"").decode())
+
+    # ---- detector ------------------------------------------------------------------------------
+    def detect(self, bgr, max_out=None):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        H, W = bgr.shape[:2]
+        max_out = max_out or self.params.max_keypoints
+        xy = np.empty((max_out, 2), np.float32)
+        desc = np.empty((max_out, 32), np.uint8)
+        octave = np.empty(max_out, np.int32)
+        angle = np.empty(max_out, np.float32)
+        resp = np.empty(max_out, np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.mslam_hip_detect(self._h, _p(bgr), W, H, max_out, _p(xy), _p(desc), _p(octave), _p(angle),
+                                          _p(resp), C.byref(n)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), desc=desc[:k].copy(), octave=octave[:k].copy(), angle=angle[:k].copy(),
+                    response=resp[:k].copy())
+
+    def detect_batch_dev(self, d_bgr_ptr, n_frames):
+        self._chk(self.L.mslam_hip_detect_batch_dev(self._h, C.c_void_p(d_bgr_ptr), int(n_frames)))
+
+    def match_batch_dev(self, ratio=0.7, chain_previous=True):
+        self._chk(self.L.mslam_hip_match_batch_dev(self._h, C.c_double(ratio), int(bool(chain_previous))))
+
+    def sync(self):
+        self._chk(self.L.mslam_hip_sync(self._h))
+
+    def batch_view(self):
+        v = BatchView()
+        self._chk(self.L.mslam_hip_get_batch_view(self._h, C.byref(v)))
+        return v
+
+    # ---- matcher -------------------------------------------------------------------------------
+    def match(self, from_desc, to_desc, ratio=0.7):
+        f = np.ascontiguousarray(from_desc, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(to_desc, np.uint8).reshape(-1, 32)
+        fi = np.empty(max(len(t), 1), np.int32)
+        ti = np.empty(max(len(t), 1), np.int32)
+        n = C.c_int(0)
+        self._chk(self.L.mslam_hip_match(self._h, _p(f), len(f), _p(t), len(t), C.c_double(ratio), _p(fi), _p(ti),
+                                         C.byref(n)))
+        return fi[:n.value].copy(), ti[:n.value].copy()
+
+    def match_knn2(self, from_desc, to_desc):
+        f = np.ascontiguousarray(from_desc, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(to_desc, np.uint8).reshape(-1, 32)
+        n = max(len(t), 1)
+        out = [np.empty(n, np.int32) for _ in range(4)]
+        self._chk(self.L.mslam_hip_match_knn2(self._h, _p(f), len(f), _p(t), len(t), *[_p(o) for o in out]))
+        return tuple(o[:len(t)].copy() for o in out)
+
+    # ---- bag of words --------------------------------------------------------------------------
+    def bow_load(self, blob):
+        b = np.frombuffer(bytes(blob), np.uint8) if not isinstance(blob, np.ndarray) else np.ascontiguousarray(blob)
+        self._chk(self.L.mslam_hip_bow_load(self._h, _p(b), C.c_size_t(b.size)))
+
+    def bow_info(self):
+        v = [C.c_int() for _ in range(6)]
+        self._chk(self.L.mslam_hip_bow_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("k", "L", "n_nodes", "n_words", "scoring", "weighting"), [x.value for x in v]))
+
+    def bow_words(self, desc):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        w = np.empty(max(len(d), 1), np.uint32)
+        wt = np.empty(max(len(d), 1), np.float64)
+        self._chk(self.L.mslam_hip_bow_words(self._h, _p(d), len(d), _p(w), _p(wt)))
+        return w[:len(d)].copy(), wt[:len(d)].copy()
+
+    def bow_transform(self, desc):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        w = np.empty(max(len(d), 1), np.uint32)
+        v = np.empty(max(len(d), 1), np.float64)
+        n = C.c_int(0)
+        self._chk(self.L.mslam_hip_bow_transform(self._h, _p(d), len(d), _p(w), _p(v), C.byref(n)))
+        return w[:n.value].copy(), v[:n.value].copy()
+
+    def bow_score(self, w1, v1, w2, v2):
+        w1 = np.ascontiguousarray(w1, np.uint32)
+        w2 = np.ascontiguousarray(w2, np.uint32)
+        v1 = np.ascontiguousarray(v1, np.float64)
+        v2 = np.ascontiguousarray(v2, np.float64)
+        s = C.c_double(0)
+        self._chk(self.L.mslam_hip_bow_score(self._h, _p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2), C.byref(s)))
+        return s.value
+
+    def bow_db_add(self, desc):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        e = C.c_int(-1)
+        self._chk(self.L.mslam_hip_bow_db_add(self._h, _p(d), len(d), C.byref(e)))
+        return e.value
+
+    def bow_db_query(self, desc, max_results=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ids = np.empty(max(max_results, 1), np.int32)
+        sc = np.empty(max(max_results, 1), np.float64)
+        n = C.c_int(0)
+        self._chk(self.L.mslam_hip_bow_db_query(self._h, _p(d), len(d), max_results, _p(ids), _p(sc), C.byref(n)))
+        return ids[:n.value].copy(), sc[:n.value].copy()
+
+    def bow_db_clear(self):
+        self._chk(self.L.mslam_hip_bow_db_clear(self._h))
+
+    def bow_batch_dev(self, add_to_db=True):
+        self._chk(self.L.mslam_hip_bow_batch_dev(self._h, int(bool(add_to_db))))
+
+    def bow_view(self):
+        v = BowView()
+        self._chk(self.L.mslam_hip_get_bow_view(self._h, C.byref(v)))
+        return v
+
+    # ---- debug ---------------------------------------------------------------------------------
+    def level_geometry(self):
+        n = self.params.n_levels
+        w = (C.c_int * 16)()
+        h = (C.c_int * 16)()
+        s = (C.c_float * 16)()
+        self._chk(self.L.mslam_hip_level_geometry(self._h, w, h, s))
+        return list(w[:n]), list(h[:n]), np.array(s[:n], np.float32)
+
+    def debug_image(self, what, frame, level):
+        w, h, _ = self.level_geometry()
+        out = np.empty((h[level], w[level]), np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.L.mslam_hip_debug_read(self._h, what, frame, level, _p(out), C.c_size_t(out.size), C.byref(n)))
+        return out
+
+    def debug_keypoints(self, what, frame, level):
+        out = np.empty((self.params.max_candidates, 3), np.float32)
+        n = C.c_size_t(0)
+        self._chk(self.L.mslam_hip_debug_read(self._h, what, frame, level, _p(out), C.c_size_t(out.nbytes),
+                                              C.byref(n)))
+        return out[:n.value].copy()
+
+    def set_profiling(self, enable):
+        self._chk(self.L.mslam_hip_set_profiling(self._h, int(bool(enable))))
+
+    def stage_times(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = C.c_int(0)
+        self._chk(self.L.mslam_hip_get_stage_times(self._h, names, ms, 32, C.byref(n)))
+        return [(names[i].decode(), ms[i]) for i in range(n.value)]
+
+
+# ---- mirrors of the reference plugin interfaces ---------------------------------------------------
+class RgbFrame:
+    """types/rgb_frame.hpp:12-16 — interleaved 3-channel bytes (B,G,R as the providers deliver them)."""
+
+    def __init__(self, data, width, height):
+        self.data = np.ascontiguousarray(data, np.uint8).reshape(height, width, 3)
+        self.size = (width, height)
+
+
+class OrbKeypoint:
+    """KeypointDescriptor<uint8_t,32> (feature_interface.hpp:18-30): keypoint {id, coordinates} + descriptor."""
+    __slots__ = ("id", "coordinates", "descriptor")
+
+    def __init__(self, id, coordinates, descriptor):
+        self.id, self.coordinates, self.descriptor = id, coordinates, descriptor
+
+
+class HipOrbDetector:
+    """IFeatureDetector<RgbFrame, uint8_t, 32> backed by the HIP extractor
+    (drop-in for DistributedOrbOpenCvDetector, distributed_cv_feature.cpp:1181-1222)."""
+
+    def __init__(self, width=640, height=480, **kw):
+        self.ctx = Context(width=width, height=height, **kw)
+
+    def detect(self, sensorData):
+        r = self.ctx.detect(sensorData.data)
+        # id = running index, coordinates widened to double (distributed_cv_feature.cpp:1203-1208)
+        return [OrbKeypoint(i, (float(x), float(y)), d) for i, ((x, y), d) in enumerate(zip(r["xy"].astype(np.float64),
+                                                                                          r["desc"]))]
+
+
+class HipOrbMatcher:
+    """IFeatureMatcher<uint8_t, 32> (drop-in for OrbOpenCvMatcher, orb_feature.cpp:84-130)."""
+
+    def __init__(self, ctx=None, ratio=0.7):
+        self.ctx = ctx or Context()
+        self.ratio = ratio
+
+    def match(self, firstDescriptors, secondDescriptors):
+        f = np.array([k.descriptor for k in firstDescriptors], np.uint8).reshape(-1, 32)
+        t = np.array([k.descriptor for k in secondDescriptors], np.uint8).reshape(-1, 32)
+        fi, ti = self.ctx.match(f, t, self.ratio)
+        return [(int(a), int(b)) for a, b in zip(fi, ti)]  # DescriptorMatch{fromIndex, toIndex}
+
+
+class HipOrbRelocalizer:
+    """IRelocalizer<SensorState, uint8_t, 32> over the DBoW3 database kernels
+    (what OrbRelocalizer is wired for, orb_relocalizer.cpp:26-50)."""
+
+    def __init__(self, vocabulary_blob, ctx=None, max_results=4):
+        self.ctx = ctx or Context()
+        self.ctx.bow_load(vocabulary_blob)
+        self.max_results = max_results
+        self._entry_to_keyframe = {}
+
+    def addKeyframe(self, keyframe, keypoints):
+        assert len(keypoints) > 0  # orb_relocalizer.cpp:42
+        d = np.array([k.descriptor for k in keypoints], np.uint8).reshape(-1, 32)
+        self._entry_to_keyframe[self.ctx.bow_db_add(d)] = keyframe
+
+    def removeKeyframe(self, keyframe):
+        for e, k in list(self._entry_to_keyframe.items()):
+            if k is keyframe:
+                del self._entry_to_keyframe[e]
+
+    def relocalize(self, keypoints):
+        d = np.array([k.descriptor for k in keypoints], np.uint8).reshape(-1, 32)
+        ids, _ = self.ctx.bow_db_query(d, self.max_results + len(self._entry_to_keyframe))
+        out = [self._entry_to_keyframe[i] for i in ids if i in self._entry_to_keyframe]
+        return out[:self.max_results]
+
+
+class HipLoopDetector:
+    """ILoopDetector<State>: detectLoop() takes no arguments (loop_detection.hpp:10-15), so it is fed
+    through the relocalizer's addKeyframe; it reports the best-scoring earlier keyframe of the most
+    recently added one, or None."""
+
+    def __init__(self, relocalizer, min_score=0.05, exclude_recent=1):
+        self.reloc = relocalizer
+        self.min_score = min_score
+        self.exclude_recent = exclude_recent
+        self._last = None
+
+    def feed(self, keyframe, keypoints):
+        d = np.array([k.descriptor for k in keypoints], np.uint8).reshape(-1, 32)
+        n_db = len(self.reloc._entry_to_keyframe)
+        ids, sc = self.reloc.ctx.bow_db_query(d, n_db) if n_db else (np.empty(0, np.int32), np.empty(0))
+        self._last = None
+        for i, s in zip(ids, sc):
+            if s >= self.min_score and i < n_db - self.exclude_recent and i in self.reloc._entry_to_keyframe:
+                self._last = self.reloc._entry_to_keyframe[i]
+                break
+        self.reloc.addKeyframe(keyframe, keypoints)
+
+    def detectLoop(self):
+        return self._last
+
+
+# ---- small HIP runtime helpers for harness code (bench / tests): raw device <-> host copies ---------
+_hiprt = None
+
+
+def _hip():
+    global _hiprt
+    if _hiprt is None:
+        _hiprt = C.CDLL("libamdhip64.so")
+    return _hiprt
+
+
+def read_device(ptr, shape, dtype):
+    """Copy a context-owned device array (raw pointer from a *_view struct) to a numpy array."""
+    out = np.empty(shape, dtype)
+    if out.nbytes:
+        rc = _hip().hipMemcpy(_p(out), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2)  # hipMemcpyDeviceToHost
+        if rc != 0:
+            raise MslamHipError(E_RUNTIME, "hipMemcpy D2H failed (%d)" % rc)
+    return out

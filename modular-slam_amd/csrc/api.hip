@@ -1,0 +1,859 @@
+// api.hip — C ABI (include/mslam_hip.h): context, host-built geometry/tables, launch sequencing.
+//
+// Host logic mirrors the scalar set-up code of the reference:
+//   level scales / sizes  : distributed_cv_feature.cpp:411-420, :836-837
+//   cell grid + skip rule : :862-905
+//   quadtree initial grid : :1031-1052
+//   resize coefficients   : cv::resize(INTER_LINEAR) table construction (OpenCV imgproc/resize.cpp)
+//   blur taps             : cv::getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (8.8)
+//   ratio-test table      : orb_feature.cpp:101 evaluated for every integer distance pair
+#include "context.hpp"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+using namespace mslam;
+
+static thread_local std::string g_create_error;
+
+#define HIPCHK(c, call)                                                                                                \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (call);                                                                                        \
+        if(e_ != hipSuccess)                                                                                           \
+        {                                                                                                              \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                              \
+            return MSLAM_HIP_E_RUNTIME;                                                                                \
+        }                                                                                                              \
+    } while(0)
+
+static int fail(mslam_hip_ctx* c, int code, const std::string& msg)
+{
+    c->err = msg;
+    return code;
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int cv_floor_f(float v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+static inline uint32_t sat_coef(float v)
+{
+    int iv = cv_round_f(v);
+    iv = iv < SHRT_MIN ? SHRT_MIN : iv > SHRT_MAX ? SHRT_MAX : iv;
+    return (uint32_t)(iv & 0xFFFF);
+}
+
+// xofs/alpha (clamp = true) or yofs/beta (clamp = false) of cv::resize INTER_LINEAR
+static void resize_table(int ssize, int dsize, bool clamp, std::vector<int32_t>& ofs, std::vector<uint32_t>& coef)
+{
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for(int d = 0; d < dsize; ++d)
+    {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cv_floor_f(f);
+        f -= s;
+        if(clamp)
+        {
+            if(s < 0)
+                f = 0, s = 0;
+            if(s >= ssize - 1)
+                f = 0, s = ssize - 1;
+        }
+        ofs.push_back(s);
+        coef.push_back(sat_coef((1.f - f) * 2048) | (sat_coef(f * 2048) << 16));
+    }
+}
+
+static void gaussian_taps_fixed(int taps[7])
+{
+    const int n = 7, n2 = 3;
+    const double sigma = 2.0, scale2x = -0.125 / (sigma * sigma);
+    double values[3], sum = 0;
+    for(int i = 0, x = 1 - n; i < n2; ++i, x += 2)
+    {
+        values[i] = std::exp((double)(x * x) * scale2x);
+        sum += values[i];
+    }
+    sum = sum * 2 + 1;
+    const double mul1 = 1.0 / sum;
+    double err = 0;
+    long total = 0;
+    for(int i = 0; i < n2; ++i)
+    {
+        const double adj = values[i] * mul1 * 256.0 + err;
+        const long v0 = lrint(adj);
+        err = adj - (double)v0;
+        taps[i] = taps[n - 1 - i] = (int)v0;
+        total += 2 * v0;
+    }
+    taps[n2] = (int)(256 - total);
+}
+
+static bool umax_table_ok()
+{
+    // orb_impl ctor, distributed_cv_feature.cpp:522-541; the kernel hard-codes the result
+    static const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    int u[17] = {0};
+    const int hp = 15;
+    const unsigned vmax = (unsigned)std::floor(hp * std::sqrt(2.0) / 2 + 1);
+    const unsigned vmin = (unsigned)std::ceil(hp * std::sqrt(2.0) / 2);
+    for(unsigned v = 0; v <= vmax; ++v)
+        u[v] = (int)std::round(std::sqrt((double)(hp * hp) - (double)(v * v)));
+    for(unsigned v = hp, v0 = 0; vmin <= v; --v)
+    {
+        while(u[v0] == u[v0 + 1])
+            ++v0;
+        u[v] = (int)v0;
+        ++v0;
+    }
+    return std::memcmp(u, expect, sizeof(expect)) == 0;
+}
+
+static int build_geometry(mslam_hip_ctx* c)
+{
+    const mslam_hip_params& p = c->p;
+    Geometry& g = c->geom;
+    g.n_levels = p.n_levels;
+    g.W = p.width;
+    g.H = p.height;
+    float scale[kMaxLevels];
+    scale[0] = 1.0f;
+    for(int l = 1; l < p.n_levels; ++l)
+        scale[l] = p.scale_factor * scale[l - 1];
+    unsigned offset = 0;
+    c->cells.clear();
+    c->tiles.clear();
+    for(int l = 0; l < p.n_levels; ++l)
+    {
+        LevelGeom& lv = g.lv[l];
+        const double s = scale[l];
+        lv.w = l == 0 ? p.width : (int)std::round(p.width * 1.0 / s);
+        lv.h = l == 0 ? p.height : (int)std::round(p.height * 1.0 / s);
+        lv.scale = scale[l];
+        if(lv.w <= 2 * kBorder + kOverlap || lv.h <= 2 * kBorder + kOverlap)
+            return fail(c, MSLAM_HIP_E_INVALID,
+                        "pyramid level " + std::to_string(l) + " is smaller than the 19-px border + one cell");
+        if(lv.w > 4095 + kBorder || lv.h > 4095 + kBorder)
+            return fail(c, MSLAM_HIP_E_INVALID, "frames larger than 4096 px per side are not supported");
+        lv.pitch = (lv.w + 15) & ~15;
+        lv.offset = (int)offset;
+        offset += ((unsigned)lv.pitch * lv.h + 255u) & ~255u;
+        lv.bw = lv.w - 2 * kBorder;
+        lv.bh = lv.h - 2 * kBorder;
+
+        // cells (:866-905)
+        const unsigned min_b = kBorder, max_bx = lv.w - kBorder, max_by = lv.h - kBorder;
+        const unsigned num_cols = (max_bx - min_b) / kCell + 1, num_rows = (max_by - min_b) / kCell + 1;
+        lv.cell_base = (int)c->cells.size();
+        for(unsigned i = 0; i < num_rows; ++i)
+        {
+            const unsigned min_y = min_b + i * kCell;
+            if(max_by - kOverlap <= min_y)
+                continue;
+            unsigned max_y = min_y + kCell + kOverlap;
+            if(max_by < max_y)
+                max_y = max_by;
+            for(unsigned j = 0; j < num_cols; ++j)
+            {
+                const unsigned min_x = min_b + j * kCell;
+                if(max_bx - kOverlap <= min_x)
+                    continue;
+                unsigned max_x = min_x + kCell + kOverlap;
+                if(max_bx < max_x)
+                    max_x = max_bx;
+                CellDesc cd{};
+                cd.level = (int16_t)l;
+                cd.cw = (int16_t)(max_x - min_x);
+                cd.ch = (int16_t)(max_y - min_y);
+                cd.x0 = (int16_t)min_x;
+                cd.y0 = (int16_t)min_y;
+                cd.ox = (int16_t)(j * kCell);
+                cd.oy = (int16_t)(i * kCell);
+                c->cells.push_back(cd);
+            }
+        }
+        lv.n_cells = (int)c->cells.size() - lv.cell_base;
+        if(lv.n_cells > 2048)
+            return fail(c, MSLAM_HIP_E_INVALID, "more than 2048 FAST cells on one level");
+
+        // blur tiles 64x32
+        lv.tile_base = (int)c->tiles.size();
+        for(int y = 0; y < lv.h; y += 32)
+            for(int x = 0; x < lv.w; x += 64)
+                c->tiles.push_back(BlurTile{(int16_t)l, (int16_t)x, (int16_t)y, 0});
+        lv.n_tiles = (int)c->tiles.size() - lv.tile_base;
+
+        // quadtree initial grid (:1031-1052) on the bordered rectangle [19, w-19) x [19, h-19)
+        const int min_x = kBorder, max_x = lv.w - kBorder, min_y = kBorder, max_y = lv.h - kBorder;
+        const double ratio = (double)(max_x - min_x) / (max_y - min_y);
+        if(ratio > 1)
+        {
+            lv.nxg = (int)std::round(ratio);
+            lv.nyg = 1;
+            lv.delta_x = (double)(max_x - min_x) / lv.nxg;
+            lv.delta_y = max_y - min_y;
+        }
+        else
+        {
+            lv.nxg = 1;
+            lv.nyg = (int)std::round(1 / ratio);
+            lv.delta_x = max_x - min_y; // sic (:1050)
+            lv.delta_y = (double)(max_y - min_y) / lv.nyg;
+        }
+        if(lv.nxg * lv.nyg > 64)
+            return fail(c, MSLAM_HIP_E_INVALID, "aspect ratio beyond 64:1 is not supported");
+    }
+    g.slab = offset + 256;
+    g.n_cells = (int)c->cells.size();
+    g.n_tiles = (int)c->tiles.size();
+    return MSLAM_HIP_OK;
+}
+
+template <typename T>
+static hipError_t dmalloc(T*& p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+}
+
+// ---- stage timing -----------------------------------------------------------------------------------
+struct StageScope
+{
+    mslam_hip_ctx* c;
+    StageTimer* t = nullptr;
+    StageScope(mslam_hip_ctx* ctx, const char* name) : c(ctx)
+    {
+        if(!c->profiling)
+            return;
+        if(c->timers_used == c->timers.size())
+        {
+            StageTimer nt{name, nullptr, nullptr};
+            if(hipEventCreate(&nt.start) != hipSuccess || hipEventCreate(&nt.stop) != hipSuccess)
+                return;
+            c->timers.push_back(nt);
+        }
+        t = &c->timers[c->timers_used++];
+        t->name = name;
+        (void)hipEventRecord(t->start, c->stream);
+    }
+    ~StageScope()
+    {
+        if(t)
+            (void)hipEventRecord(t->stop, c->stream);
+    }
+};
+
+// ---- C ABI ------------------------------------------------------------------------------------------
+extern "C" {
+
+void mslam_hip_default_params(mslam_hip_params* p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->width = 640;
+    p->height = 480;
+    p->max_batch = 1;
+    p->n_levels = 8;        // distributed_cv_feature.cpp:1184
+    p->scale_factor = 1.2f; // :1184
+    p->ini_fast_thr = 20;
+    p->min_fast_thr = 7;
+    p->min_node_area = 1000; // :1186
+    p->max_keypoints = 8192;
+    p->max_candidates = 16384;
+    p->device = 0;
+    p->stream = nullptr;
+}
+
+int mslam_hip_abi_version(void) { return MSLAM_HIP_ABI_VERSION; }
+
+const char* mslam_hip_last_error(const mslam_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void mslam_hip_destroy(mslam_hip_ctx* c)
+{
+    if(!c)
+        return;
+    if(c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->d_cells,   c->d_tiles,  c->d_rs_ofs, c->d_rs_coef, c->d_ratio_thr, c->d_stage,  c->d_pyr,
+                    c->d_blur,    c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
+                    c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
+                    c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_xy, c->d_desc, c->d_octave,
+                    c->d_angle,   c->d_response, c->d_count, c->d_idx0, c->d_idx1, c->d_dist0, c->d_dist1, c->d_mfrom,
+                    c->d_mto,     c->d_mcount, c->d_hm_from, c->d_hm_to, c->d_hm_out};
+    for(void* b : bufs)
+        if(b)
+            (void)hipFree(b);
+    for(auto& t : c->timers)
+    {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    if(c->bow)
+        bow_destroy(c->bow);
+    if(c->own_stream && c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(mslam_hip_ctx* c)
+{
+    const mslam_hip_params& p = c->p;
+    if(p.width <= 0 || p.height <= 0 || p.max_batch < 1 || p.n_levels < 1 || p.n_levels > kMaxLevels ||
+       !(p.scale_factor > 1.0f) || p.ini_fast_thr < 0 || p.ini_fast_thr > 255 || p.min_fast_thr < 0 ||
+       p.min_fast_thr > p.ini_fast_thr || p.max_keypoints < 1 || p.max_candidates < 1 ||
+       p.max_candidates > (1 << 22))
+        return fail(c, MSLAM_HIP_E_INVALID, "invalid parameters");
+    if(!umax_table_ok())
+        return fail(c, MSLAM_HIP_E_INVALID, "u_max table self-check failed");
+    int taps[7];
+    gaussian_taps_fixed(taps);
+    static const int expect_taps[7] = {18, 34, 48, 56, 48, 34, 18};
+    if(std::memcmp(taps, expect_taps, sizeof(taps)) != 0)
+        return fail(c, MSLAM_HIP_E_INVALID, "gaussian tap self-check failed");
+    set_blur_taps(taps);
+
+    int rc = build_geometry(c);
+    if(rc)
+        return rc;
+    const Geometry& g = c->geom;
+
+    int n_dev = 0;
+    if(hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(c, MSLAM_HIP_E_RUNTIME, "no HIP device available (the product path has no CPU fallback)");
+    HIPCHK(c, hipSetDevice(p.device));
+    if(p.stream)
+        c->stream = (hipStream_t)p.stream;
+    else
+    {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+
+    // tables
+    HIPCHK(c, dmalloc(c->d_cells, c->cells.size()));
+    HIPCHK(c, hipMemcpy(c->d_cells, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    HIPCHK(c, dmalloc(c->d_tiles, c->tiles.size()));
+    HIPCHK(c, hipMemcpy(c->d_tiles, c->tiles.data(), c->tiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> ofs;
+        std::vector<uint32_t> coef;
+        c->rs_x.assign(p.n_levels, 0);
+        c->rs_y.assign(p.n_levels, 0);
+        for(int l = 1; l < p.n_levels; ++l)
+        {
+            c->rs_x[l] = ofs.size();
+            resize_table(g.lv[l - 1].w, g.lv[l].w, true, ofs, coef);
+            c->rs_y[l] = ofs.size();
+            resize_table(g.lv[l - 1].h, g.lv[l].h, false, ofs, coef);
+        }
+        ofs.push_back(0);
+        coef.push_back(0);
+        HIPCHK(c, dmalloc(c->d_rs_ofs, ofs.size()));
+        HIPCHK(c, dmalloc(c->d_rs_coef, coef.size()));
+        HIPCHK(c, hipMemcpy(c->d_rs_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_rs_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, dmalloc(c->d_ratio_thr, 257));
+
+    const size_t B = (size_t)p.max_batch, L = (size_t)p.n_levels, cap = (size_t)p.max_candidates;
+    const size_t K = (size_t)p.max_keypoints;
+    HIPCHK(c, dmalloc(c->d_stage, (size_t)p.width * p.height * 3));
+    HIPCHK(c, dmalloc(c->d_pyr, B * g.slab));
+    HIPCHK(c, dmalloc(c->d_blur, B * g.slab));
+    HIPCHK(c, dmalloc(c->d_cell_cnt, B * g.n_cells));
+    HIPCHK(c, dmalloc(c->d_cell_kp, B * g.n_cells * (size_t)kCellCap));
+    QuadArgs& q = c->quad;
+    HIPCHK(c, dmalloc(q.cand, B * L * cap));
+    HIPCHK(c, dmalloc(q.cand_cnt, B * L));
+    HIPCHK(c, dmalloc(q.sel, B * L * cap));
+    HIPCHK(c, dmalloc(q.sel_cnt, B * L));
+    HIPCHK(c, dmalloc(q.kp_node, B * L * cap));
+    HIPCHK(c, dmalloc(q.nodes_a, B * L * cap));
+    HIPCHK(c, dmalloc(q.nodes_b, B * L * cap));
+    HIPCHK(c, dmalloc(q.ncnt_a, B * L * cap));
+    HIPCHK(c, dmalloc(q.ncnt_b, B * L * cap));
+    HIPCHK(c, dmalloc(q.child_cnt, B * L * cap * 4));
+    HIPCHK(c, dmalloc(q.ninfo, B * L * cap));
+    HIPCHK(c, dmalloc(q.best, B * L * cap));
+    HIPCHK(c, dmalloc(c->d_flags, 1));
+    HIPCHK(c, hipMemset(c->d_flags, 0, 4));
+    q.cell_cnt = c->d_cell_cnt;
+    q.cell_kp = c->d_cell_kp;
+    q.flags = c->d_flags;
+    q.cand_cap = p.max_candidates;
+    q.min_size = p.min_node_area;
+
+    HIPCHK(c, dmalloc(c->d_xy, (B + 1) * K * 2));
+    HIPCHK(c, dmalloc(c->d_desc, (B + 1) * K * 32));
+    HIPCHK(c, dmalloc(c->d_octave, (B + 1) * K));
+    HIPCHK(c, dmalloc(c->d_angle, (B + 1) * K));
+    HIPCHK(c, dmalloc(c->d_response, (B + 1) * K));
+    HIPCHK(c, dmalloc(c->d_count, B + 1));
+    HIPCHK(c, hipMemset(c->d_count, 0, (B + 1) * 4));
+    HIPCHK(c, dmalloc(c->d_idx0, B * K));
+    HIPCHK(c, dmalloc(c->d_idx1, B * K));
+    HIPCHK(c, dmalloc(c->d_dist0, B * K));
+    HIPCHK(c, dmalloc(c->d_dist1, B * K));
+    HIPCHK(c, dmalloc(c->d_mfrom, B * K));
+    HIPCHK(c, dmalloc(c->d_mto, B * K));
+    HIPCHK(c, dmalloc(c->d_mcount, B));
+    HIPCHK(c, hipMemset(c->d_mcount, 0, B * 4));
+    HIPCHK(c, hipDeviceSynchronize());
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_create(const mslam_hip_params* p, mslam_hip_ctx** out)
+{
+    if(!p || !out)
+    {
+        g_create_error = "null argument";
+        return MSLAM_HIP_E_INVALID;
+    }
+    *out = nullptr;
+    mslam_hip_ctx* c = new mslam_hip_ctx();
+    c->p = *p;
+    const int rc = create_impl(c);
+    if(rc != MSLAM_HIP_OK)
+    {
+        g_create_error = c->err;
+        mslam_hip_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return MSLAM_HIP_OK;
+}
+
+static int check_flags(mslam_hip_ctx* c)
+{
+    uint32_t f = 0;
+    HIPCHK(c, hipMemcpyAsync(&f, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if(f == 0)
+        return MSLAM_HIP_OK;
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4, c->stream));
+    std::string m = "capacity exceeded:";
+    if(f & kFlagCandOverflow)
+        m += " FAST candidates on a level > max_candidates;";
+    if(f & kFlagKpOverflow)
+        m += " keypoints in a frame > max_keypoints;";
+    if(f & kFlagQuadNoConverge)
+        m += " quadtree pass limit;";
+    return fail(c, MSLAM_HIP_E_CAPACITY, m);
+}
+
+int mslam_hip_sync(mslam_hip_ctx* c)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    return check_flags(c);
+}
+
+int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(!d_bgr || n_frames < 1 || n_frames > c->p.max_batch)
+        return fail(c, MSLAM_HIP_E_INVALID, "detect_batch_dev: n_frames outside [1, max_batch]");
+    const Geometry& g = c->geom;
+    const size_t K = (size_t)c->p.max_keypoints;
+    hipStream_t s = c->stream;
+    c->timers_used = 0;
+
+    // carry the last frame of the previous batch into slot 0 (predecessor of the new frame 0)
+    if(c->n_last > 0)
+    {
+        const size_t last = (size_t)c->n_last;
+        HIPCHK(c, hipMemcpyAsync(c->d_desc, c->d_desc + last * K * 32, K * 32, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_count, c->d_count + last, 4, hipMemcpyDeviceToDevice, s));
+        c->have_prev = true;
+    }
+    {
+        StageScope t(c, "gray");
+        launch_gray(d_bgr, c->d_pyr, g, n_frames, s);
+    }
+    {
+        StageScope t(c, "resize");
+        for(int l = 1; l < g.n_levels; ++l)
+            launch_resize(c->d_pyr, g, l, c->d_rs_ofs + c->rs_x[l], c->d_rs_coef + c->rs_x[l], c->d_rs_ofs + c->rs_y[l],
+                          c->d_rs_coef + c->rs_y[l], n_frames, s);
+    }
+    {
+        StageScope t(c, "fast");
+        launch_fast(c->d_pyr, g, c->d_cells, c->d_cell_cnt, c->d_cell_kp, c->p.ini_fast_thr, c->p.min_fast_thr,
+                    n_frames, s);
+    }
+    {
+        StageScope t(c, "quadtree");
+        launch_quadtree(g, c->quad, n_frames, s);
+    }
+    {
+        StageScope t(c, "blur");
+        launch_blur(c->d_pyr, c->d_blur, g, c->d_tiles, n_frames, s);
+    }
+    {
+        StageScope t(c, "describe");
+        DescArgs a{};
+        a.pyr = c->d_pyr;
+        a.blur = c->d_blur;
+        a.sel = c->quad.sel;
+        a.sel_cnt = c->quad.sel_cnt;
+        a.cand_cap = c->p.max_candidates;
+        a.max_kp = c->p.max_keypoints;
+        a.xy = c->d_xy + K * 2;
+        a.desc = c->d_desc + K * 32;
+        a.octave = c->d_octave + K;
+        a.angle = c->d_angle + K;
+        a.response = c->d_response + K;
+        a.count = c->d_count + 1;
+        a.flags = c->d_flags;
+        launch_describe(g, a, n_frames, s);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->n_last = n_frames;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_get_batch_view(mslam_hip_ctx* c, mslam_hip_batch_view* v)
+{
+    if(!c || !v)
+        return MSLAM_HIP_E_INVALID;
+    const size_t K = (size_t)c->p.max_keypoints;
+    v->n_frames = c->n_last;
+    v->capacity = c->p.max_keypoints;
+    v->xy = c->d_xy + K * 2;
+    v->desc = c->d_desc + K * 32;
+    v->octave = c->d_octave + K;
+    v->angle = c->d_angle + K;
+    v->response = c->d_response + K;
+    v->count = c->d_count + 1;
+    v->match_from = c->d_mfrom;
+    v->match_to = c->d_mto;
+    v->match_count = c->d_mcount;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height, int max_out, float* xy,
+                     uint8_t* desc, int32_t* octave, float* angle, float* response, int* n_out)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(n_out)
+        *n_out = 0;
+    if(!bgr || !n_out || max_out < 0 || (max_out > 0 && (!xy || !desc)))
+        return fail(c, MSLAM_HIP_E_INVALID, "detect: null argument");
+    if(width != c->p.width || height != c->p.height)
+        return fail(c, MSLAM_HIP_E_INVALID, "detect: frame size differs from the context's");
+    const size_t K = (size_t)c->p.max_keypoints;
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, bgr, (size_t)width * height * 3, hipMemcpyHostToDevice, c->stream));
+    int rc = mslam_hip_detect_batch_dev(c, c->d_stage, 1);
+    if(rc)
+        return rc;
+    int32_t n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, c->d_count + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    rc = check_flags(c); // synchronises
+    if(rc)
+        return rc;
+    *n_out = n;
+    if(n > max_out)
+        return fail(c, MSLAM_HIP_E_CAPACITY, "detect: max_out smaller than the number of keypoints");
+    if(n == 0)
+        return MSLAM_HIP_OK;
+    HIPCHK(c, hipMemcpy(xy, c->d_xy + K * 2, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(desc, c->d_desc + K * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if(octave)
+        HIPCHK(c, hipMemcpy(octave, c->d_octave + K, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if(angle)
+        HIPCHK(c, hipMemcpy(angle, c->d_angle + K, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if(response)
+        HIPCHK(c, hipMemcpy(response, c->d_response + K, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return MSLAM_HIP_OK;
+}
+
+// ---- matcher ----------------------------------------------------------------------------------------
+static int upload_ratio_table(mslam_hip_ctx* c, double ratio)
+{
+    if(ratio == c->ratio_cached)
+        return MSLAM_HIP_OK;
+    // thr[d1] = number of integer d0 in [0,256] with (double)(float)d0 < ratio*(double)(float)d1
+    // (orb_feature.cpp:101; DMatch::distance is a float holding the integer Hamming distance)
+    int32_t thr[257];
+    for(int d1 = 0; d1 <= 256; ++d1)
+    {
+        int n = 0;
+        for(int d0 = 0; d0 <= 256; ++d0)
+            if((double)(float)d0 < ratio * (double)(float)d1)
+                ++n;
+            else
+                break;
+        thr[d1] = n;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ratio_thr, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // thr is a stack buffer
+    c->ratio_cached = ratio;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(c->n_last < 1)
+        return fail(c, MSLAM_HIP_E_INVALID, "match_batch_dev: no detect batch to match");
+    int rc = upload_ratio_table(c, ratio);
+    if(rc)
+        return rc;
+    const size_t K = (size_t)c->p.max_keypoints;
+    const int first = (chain_previous && c->have_prev) ? 0 : 1; // first frame that has a predecessor
+    const int n_pairs = c->n_last - first;
+    hipStream_t s = c->stream;
+    if(first == 1)
+        HIPCHK(c, hipMemsetAsync(c->d_mcount, 0, 4, s));
+    if(n_pairs > 0)
+    {
+        MatchArgs m{};
+        // pair t: from = frame t (slot t+1), to = frame t-1 (slot t)
+        m.from_desc = c->d_desc + (size_t)(first + 1) * K * 32;
+        m.to_desc = c->d_desc + (size_t)first * K * 32;
+        m.from_stride = m.to_stride = (long long)K * 32;
+        m.from_cnt = c->d_count + first + 1;
+        m.to_cnt = c->d_count + first;
+        m.cap = c->p.max_keypoints;
+        m.idx0 = c->d_idx0 + (size_t)first * K;
+        m.idx1 = c->d_idx1 + (size_t)first * K;
+        m.dist0 = c->d_dist0 + (size_t)first * K;
+        m.dist1 = c->d_dist1 + (size_t)first * K;
+        {
+            StageScope t(c, "match_knn2");
+            launch_match_knn2(m, n_pairs, s);
+        }
+        RatioArgs r{};
+        r.idx0 = m.idx0;
+        r.dist0 = m.dist0;
+        r.dist1 = m.dist1;
+        r.from_cnt = m.from_cnt;
+        r.to_cnt = m.to_cnt;
+        r.cap = m.cap;
+        r.thr = c->d_ratio_thr;
+        r.from_idx = c->d_mfrom + (size_t)first * K;
+        r.to_idx = c->d_mto + (size_t)first * K;
+        r.n_out = c->d_mcount + first;
+        {
+            StageScope t(c, "ratio_compact");
+            launch_ratio_compact(r, n_pairs, s);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
+static int host_match_prepare(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to)
+{
+    if(n_from > c->hm_from_cap)
+    {
+        if(c->d_hm_from)
+            (void)hipFree(c->d_hm_from);
+        c->d_hm_from = nullptr;
+        c->hm_from_cap = 0;
+        HIPCHK(c, dmalloc(c->d_hm_from, (size_t)n_from * 32));
+        c->hm_from_cap = n_from;
+    }
+    if(n_to > c->hm_to_cap)
+    {
+        if(c->d_hm_to)
+            (void)hipFree(c->d_hm_to);
+        if(c->d_hm_out)
+            (void)hipFree(c->d_hm_out);
+        c->d_hm_to = nullptr;
+        c->d_hm_out = nullptr;
+        c->hm_to_cap = 0;
+        HIPCHK(c, dmalloc(c->d_hm_to, (size_t)n_to * 32));
+        HIPCHK(c, dmalloc(c->d_hm_out, (size_t)n_to * 6 + 4));
+        c->hm_to_cap = n_to;
+    }
+    if(n_from > 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_hm_from, from_desc, (size_t)n_from * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_hm_to, to_desc, (size_t)n_to * 32, hipMemcpyHostToDevice, c->stream));
+    return MSLAM_HIP_OK;
+}
+
+static void host_match_args(mslam_hip_ctx* c, int n_from, int n_to, MatchArgs& m)
+{
+    const size_t cap = (size_t)c->hm_to_cap;
+    m = MatchArgs{};
+    m.from_desc = c->d_hm_from;
+    m.to_desc = c->d_hm_to;
+    m.n_from_fixed = n_from;
+    m.n_to_fixed = n_to;
+    m.cap = n_to;
+    m.idx0 = c->d_hm_out;
+    m.idx1 = c->d_hm_out + cap;
+    m.dist0 = c->d_hm_out + 2 * cap;
+    m.dist1 = c->d_hm_out + 3 * cap;
+}
+
+int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,
+                         int32_t* idx0, int32_t* idx1, int32_t* dist0, int32_t* dist1)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(n_from < 0 || n_to < 0 || (n_from > 0 && !from_desc) || (n_to > 0 && (!to_desc || !idx0 || !idx1 || !dist0 || !dist1)))
+        return fail(c, MSLAM_HIP_E_INVALID, "match_knn2: bad argument");
+    if(n_to == 0)
+        return MSLAM_HIP_OK;
+    int rc = host_match_prepare(c, from_desc, n_from, to_desc, n_to);
+    if(rc)
+        return rc;
+    MatchArgs m;
+    host_match_args(c, n_from, n_to, m);
+    launch_match_knn2(m, 1, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(idx0, m.idx0, (size_t)n_to * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(idx1, m.idx1, (size_t)n_to * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dist0, m.dist0, (size_t)n_to * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dist1, m.dist1, (size_t)n_to * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,
+                    double ratio, int32_t* from_idx, int32_t* to_idx, int* n_out)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(n_out)
+        *n_out = 0;
+    if(!n_out || n_from < 0 || n_to < 0 || (n_from > 0 && !from_desc) || (n_to > 0 && (!to_desc || !from_idx || !to_idx)))
+        return fail(c, MSLAM_HIP_E_INVALID, "match: bad argument");
+    if(n_to == 0 || n_from < 2)
+        return MSLAM_HIP_OK; // reference: UB for n_from < 2 (orb_feature.cpp:101); defined here as no matches
+    int rc = upload_ratio_table(c, ratio);
+    if(rc)
+        return rc;
+    rc = host_match_prepare(c, from_desc, n_from, to_desc, n_to);
+    if(rc)
+        return rc;
+    MatchArgs m;
+    host_match_args(c, n_from, n_to, m);
+    launch_match_knn2(m, 1, c->stream);
+    const size_t cap = (size_t)c->hm_to_cap;
+    RatioArgs r{};
+    r.idx0 = m.idx0;
+    r.dist0 = m.dist0;
+    r.dist1 = m.dist1;
+    r.n_from_fixed = n_from;
+    r.n_to_fixed = n_to;
+    r.cap = n_to;
+    r.thr = c->d_ratio_thr;
+    r.from_idx = c->d_hm_out + 4 * cap;
+    r.to_idx = c->d_hm_out + 5 * cap;
+    r.n_out = c->d_hm_out + 6 * cap;
+    launch_ratio_compact(r, 1, c->stream);
+    HIPCHK(c, hipGetLastError());
+    int32_t n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, r.n_out, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if(n > 0)
+    {
+        HIPCHK(c, hipMemcpy(from_idx, r.from_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(to_idx, r.to_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return MSLAM_HIP_OK;
+}
+
+// ---- debug / test access ----------------------------------------------------------------------------
+int mslam_hip_level_geometry(mslam_hip_ctx* c, int* widths, int* heights, float* scales)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    for(int l = 0; l < c->geom.n_levels; ++l)
+    {
+        if(widths)
+            widths[l] = c->geom.lv[l].w;
+        if(heights)
+            heights[l] = c->geom.lv[l].h;
+        if(scales)
+            scales[l] = c->geom.lv[l].scale;
+    }
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void* dst, size_t dst_bytes,
+                         size_t* n_items)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(frame < 0 || frame >= c->p.max_batch || level < 0 || level >= c->geom.n_levels || !dst || !n_items)
+        return fail(c, MSLAM_HIP_E_INVALID, "debug_read: bad argument");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const LevelGeom& lv = c->geom.lv[level];
+    if(what == MSLAM_HIP_DBG_PYRAMID || what == MSLAM_HIP_DBG_BLURRED)
+    {
+        const size_t need = (size_t)lv.w * lv.h;
+        *n_items = need;
+        if(dst_bytes < need)
+            return fail(c, MSLAM_HIP_E_CAPACITY, "debug_read: buffer too small");
+        const uint8_t* src = (what == MSLAM_HIP_DBG_PYRAMID ? c->d_pyr : c->d_blur) + (size_t)frame * c->geom.slab + lv.offset;
+        HIPCHK(c, hipMemcpy2D(dst, lv.w, src, lv.pitch, lv.w, lv.h, hipMemcpyDeviceToHost));
+        return MSLAM_HIP_OK;
+    }
+    if(what == MSLAM_HIP_DBG_CANDIDATES || what == MSLAM_HIP_DBG_SELECTED)
+    {
+        const size_t slot = (size_t)frame * c->geom.n_levels + level;
+        const bool cand = what == MSLAM_HIP_DBG_CANDIDATES;
+        uint32_t n = 0;
+        HIPCHK(c, hipMemcpy(&n, (cand ? c->quad.cand_cnt : c->quad.sel_cnt) + slot, 4, hipMemcpyDeviceToHost));
+        *n_items = n;
+        if(dst_bytes < (size_t)n * 12)
+            return fail(c, MSLAM_HIP_E_CAPACITY, "debug_read: buffer too small");
+        std::vector<uint32_t> tmp(n);
+        if(n)
+            HIPCHK(c, hipMemcpy(tmp.data(), (cand ? c->quad.cand : c->quad.sel) + slot * (size_t)c->p.max_candidates,
+                                (size_t)n * 4, hipMemcpyDeviceToHost));
+        float* out = static_cast<float*>(dst);
+        for(uint32_t i = 0; i < n; ++i)
+        {
+            out[3 * i] = (float)kp_x(tmp[i]);
+            out[3 * i + 1] = (float)kp_y(tmp[i]);
+            out[3 * i + 2] = (float)kp_score(tmp[i]);
+        }
+        return MSLAM_HIP_OK;
+    }
+    return fail(c, MSLAM_HIP_E_INVALID, "debug_read: unknown item");
+}
+
+int mslam_hip_set_profiling(mslam_hip_ctx* c, int enable)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    c->profiling = enable != 0;
+    c->timers_used = 0;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_get_stage_times(mslam_hip_ctx* c, const char** names, float* ms, int cap, int* n)
+{
+    if(!c || !n)
+        return MSLAM_HIP_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int k = 0;
+    for(size_t i = 0; i < c->timers_used && k < cap; ++i, ++k)
+    {
+        float t = 0;
+        HIPCHK(c, hipEventElapsedTime(&t, c->timers[i].start, c->timers[i].stop));
+        if(names)
+            names[k] = c->timers[i].name;
+        if(ms)
+            ms[k] = t;
+    }
+    *n = k;
+    return MSLAM_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,151 @@
+// common.hpp — shared declarations of the gfx950 kernels and the context behind the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+
+namespace mslam
+{
+
+constexpr int kMaxLevels = 16;
+constexpr int kBorder = 19;    // orb_patch_radius_, reference distributed_cv_feature.cpp:699
+constexpr int kCell = 64;      // cell_size, :853
+constexpr int kOverlap = 6;    // overlap,   :852
+constexpr int kCellCap = 1024; // NMS keeps at most one corner per 2x2 block of a 64x64 tested area
+
+// One pyramid level inside a frame's slab.  All fields are filled on the host at context creation.
+struct LevelGeom
+{
+    int w, h;       // level size in pixels (reference :836-837)
+    int pitch;      // row pitch in bytes (multiple of 16)
+    int offset;     // byte offset of the level inside the frame slab
+    float scale;    // scale_factors_[l], float32 chain (:411-420)
+    int bw, bh;     // bordered width/height = w-38, h-38
+    int cell_base;  // index of this level's first cell in the cell table
+    int n_cells;    // cells kept after the skip rule (:881-905)
+    int tile_base;  // first blur tile of this level
+    int n_tiles;
+    // quadtree initial grid (:1031-1052)
+    int nxg, nyg;
+    double delta_x, delta_y;
+};
+
+struct Geometry
+{
+    int n_levels;
+    int W, H;
+    int n_cells, n_tiles;
+    unsigned slab; // bytes per frame (all levels)
+    LevelGeom lv[kMaxLevels];
+};
+
+// FAST cell: a sub-image [x0, x0+cw) x [y0, y0+ch) of one level (:880-905).
+struct CellDesc
+{
+    int16_t level, cw, ch, pad;
+    int16_t x0, y0; // absolute level coordinates of the sub-image origin (min_x, min_y)
+    int16_t ox, oy; // j*64, i*64: added to cell-relative coordinates (:940-941)
+};
+
+struct BlurTile
+{
+    int16_t level, x0, y0, pad;
+};
+
+// candidate / selected keypoint: (Y << 20) | (X << 8) | score, X/Y relative to the (19,19) border origin
+__host__ __device__ inline uint32_t pack_kp(int x, int y, int score) { return ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)score; }
+__host__ __device__ inline int kp_x(uint32_t p) { return (int)((p >> 8) & 0xFFFu); }
+__host__ __device__ inline int kp_y(uint32_t p) { return (int)(p >> 20); }
+__host__ __device__ inline int kp_score(uint32_t p) { return (int)(p & 0xFFu); }
+
+// status flags written by kernels (device word, OR-ed)
+enum : uint32_t
+{
+    kFlagCandOverflow = 1u,  // more FAST candidates on a level than max_candidates
+    kFlagKpOverflow = 2u,    // more keypoints in a frame than max_keypoints
+    kFlagQuadNoConverge = 4u // quadtree pass limit hit (cannot happen for sane sizes)
+};
+
+// ---- kernel launchers (each enqueues on `s`, no synchronisation) ----------------------------------
+void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int n_frames, hipStream_t s);
+void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,
+                   const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s);
+void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
+                 uint32_t* d_cell_kp, int ini_thr, int min_thr, int n_frames, hipStream_t s);
+struct QuadArgs
+{
+    const uint32_t* cell_cnt; // [B][n_cells]
+    const uint32_t* cell_kp;  // [B][n_cells][kCellCap]
+    uint32_t* cand;           // [B][L][cand_cap]   packed candidates in FAST order
+    uint32_t* cand_cnt;       // [B][L]
+    uint32_t* sel;            // [B][L][cand_cap]   packed selected keypoints in node-list order
+    uint32_t* sel_cnt;        // [B][L]
+    // scratch, per (frame, level) block:
+    uint32_t* kp_node;  // [B][L][cand_cap]
+    uint2* nodes_a;     // [B][L][cand_cap]  (bx|by<<16, ex|ey<<16)
+    uint2* nodes_b;
+    uint32_t* ncnt_a;   // [B][L][cand_cap]  keypoints per node
+    uint32_t* ncnt_b;
+    uint32_t* child_cnt; // [B][L][cand_cap*4]
+    uint32_t* ninfo;     // [B][L][cand_cap]
+    uint32_t* best;      // [B][L][cand_cap]
+    uint32_t* flags;     // status word
+    int cand_cap;
+    unsigned min_size;
+};
+void launch_quadtree(const Geometry& g, const QuadArgs& a, int n_frames, hipStream_t s);
+void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, const BlurTile* d_tiles, int n_frames,
+                 hipStream_t s);
+struct DescArgs
+{
+    const uint8_t* pyr;
+    const uint8_t* blur;
+    const uint32_t* sel;
+    const uint32_t* sel_cnt;
+    int cand_cap;
+    int max_kp;
+    float* xy;
+    uint8_t* desc;
+    int32_t* octave;
+    float* angle;
+    float* response;
+    int32_t* count;
+    uint32_t* flags;
+};
+void launch_describe(const Geometry& g, const DescArgs& a, int n_frames, hipStream_t s);
+
+// knn-2 Hamming match for `n_pairs` independent (from, to) pairs.  Descriptor sets are addressed as
+// base + pair_index * stride; counts come from device arrays (or fixed values when the pointer is null).
+struct MatchArgs
+{
+    const uint8_t* from_desc;
+    const uint8_t* to_desc;
+    long long from_stride, to_stride; // bytes between consecutive pairs
+    const int32_t* from_cnt;          // [n_pairs] (stride 1) or nullptr -> n_from_fixed
+    const int32_t* to_cnt;
+    int n_from_fixed, n_to_fixed;
+    int cap;          // per-pair capacity of the outputs (max n_to)
+    int32_t* idx0;    // [n_pairs][cap]
+    int32_t* idx1;
+    int32_t* dist0;
+    int32_t* dist1;
+};
+void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s);
+// ratio test + ordered compaction (orb_feature.cpp:99-114).  thr[d1] = largest d0 accepted + 1.
+struct RatioArgs
+{
+    const int32_t* idx0;
+    const int32_t* dist0;
+    const int32_t* dist1;
+    const int32_t* from_cnt;
+    const int32_t* to_cnt;
+    int n_from_fixed, n_to_fixed;
+    int cap;
+    const int32_t* thr; // [257]: accept iff d0 < thr[d1]
+    int32_t* from_idx;  // [n_pairs][cap]
+    int32_t* to_idx;
+    int32_t* n_out;     // [n_pairs]
+};
+void launch_ratio_compact(const RatioArgs& a, int n_pairs, hipStream_t s);
+
+} // namespace mslam

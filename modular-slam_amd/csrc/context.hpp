@@ -1,0 +1,80 @@
+// context.hpp — the object behind mslam_hip_ctx: host-built tables, device buffers, stream.
+#pragma once
+#include "common.hpp"
+#include "../../include/mslam_hip.h"
+#include <string>
+#include <vector>
+
+namespace mslam
+{
+struct BowState; // k_bow.hip
+void bow_destroy(BowState*);
+void set_blur_taps(const int* taps);
+
+struct StageTimer
+{
+    const char* name;
+    hipEvent_t start, stop;
+};
+} // namespace mslam
+
+struct mslam_hip_ctx
+{
+    mslam_hip_params p{};
+    mslam::Geometry geom{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // host copies of the tables
+    std::vector<mslam::CellDesc> cells;
+    std::vector<mslam::BlurTile> tiles;
+
+    // device tables
+    mslam::CellDesc* d_cells = nullptr;
+    mslam::BlurTile* d_tiles = nullptr;
+    int32_t* d_rs_ofs = nullptr;   // resize offsets, all levels
+    uint32_t* d_rs_coef = nullptr; // resize coefficients, all levels
+    std::vector<size_t> rs_x, rs_y; // per-level start index into d_rs_*
+    int32_t* d_ratio_thr = nullptr; // [257]
+    double ratio_cached = -1.0;
+
+    // device working set (sized for max_batch frames)
+    uint8_t* d_stage = nullptr; // one frame of BGR for the host-pointer entry point
+    uint8_t* d_pyr = nullptr;
+    uint8_t* d_blur = nullptr;
+    uint32_t* d_cell_cnt = nullptr;
+    uint32_t* d_cell_kp = nullptr;
+    mslam::QuadArgs quad{};
+    uint32_t* d_flags = nullptr;
+
+    // outputs: slot 0 = last frame of the previous batch, slots 1..max_batch = current batch
+    float* d_xy = nullptr;
+    uint8_t* d_desc = nullptr;
+    int32_t* d_octave = nullptr;
+    float* d_angle = nullptr;
+    float* d_response = nullptr;
+    int32_t* d_count = nullptr;
+    int n_last = 0;         // frames in the last detect batch
+    bool have_prev = false; // slot 0 holds a real predecessor of the current batch
+
+    // matcher
+    int32_t *d_idx0 = nullptr, *d_idx1 = nullptr, *d_dist0 = nullptr, *d_dist1 = nullptr;
+    int32_t *d_mfrom = nullptr, *d_mto = nullptr, *d_mcount = nullptr;
+    // host-pointer matcher scratch (grown on demand)
+    uint8_t *d_hm_from = nullptr, *d_hm_to = nullptr;
+    int32_t* d_hm_out = nullptr; // 6 arrays x cap + 1
+    int hm_from_cap = 0, hm_to_cap = 0;
+
+    mslam::BowState* bow = nullptr;
+
+    bool profiling = false;
+    std::vector<mslam::StageTimer> timers;
+    size_t timers_used = 0;
+};
+
+namespace mslam
+{
+// bow entry points used by api.hip
+int bow_batch(mslam_hip_ctx* c, int add_to_db);
+} // namespace mslam

@@ -1,0 +1,124 @@
+// k_pyramid.hip — BGR -> gray (pyramid level 0) and the chained fixed-point bilinear pyramid.
+//
+// gray   : reference frame.cpp:6-27 (toGrayScale); float mul/add left to right, no FMA, truncation.
+// resize : cv::resize(INTER_LINEAR, CV_8UC1) as called at distributed_cv_feature.cpp:839; the
+//          coefficient tables are built on the host (api.hip) exactly as cv::resize builds them,
+//          the kernel does the integer interpolation (HResizeLinear / VResizeLinear<uchar,...>).
+//
+// Both are streaming, HBM-bound kernels: 4 pixels per lane, dword loads/stores, rows coalesced.
+#include "common.hpp"
+
+namespace mslam
+{
+
+__device__ __forceinline__ uint32_t gray_px(uint32_t c0, uint32_t c1, uint32_t c2)
+{
+    // (0.299f*c0 + 0.587f*c1) + 0.114f*c2 with every operation individually rounded (no contraction)
+    float v = __fadd_rn(__fmul_rn(0.299f, (float)c0), __fmul_rn(0.587f, (float)c1));
+    v = __fadd_rn(v, __fmul_rn(0.114f, (float)c2));
+    v = fminf(255.0f, v);
+    return (uint32_t)(int)v; // static_cast<uint8_t> of a non-negative float: truncation
+}
+
+// W % 4 == 0: one lane converts 4 pixels = 12 source bytes (3 aligned dwords) -> 1 dword.
+__global__ __launch_bounds__(256) void k_gray4(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ pyr, int W, int H,
+                                               int pitch, unsigned slab)
+{
+    const int quad = blockIdx.x * 256 + threadIdx.x;
+    const int n_quads = (W * H) >> 2;
+    if(quad >= n_quads)
+        return;
+    const size_t frame = blockIdx.y;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(bgr + frame * (size_t)W * H * 3) + (size_t)quad * 3;
+    const uint32_t a = src[0], b = src[1], c = src[2];
+    // bytes: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3   (little endian)
+    const uint32_t p0 = gray_px(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
+    const uint32_t p1 = gray_px(a >> 24, b & 0xFF, (b >> 8) & 0xFF);
+    const uint32_t p2 = gray_px((b >> 16) & 0xFF, b >> 24, c & 0xFF);
+    const uint32_t p3 = gray_px((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24);
+    const int px = quad << 2;
+    const int y = px / W, x = px - y * W;
+    *reinterpret_cast<uint32_t*>(pyr + frame * slab + (size_t)y * pitch + x) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+}
+
+// generic width: one pixel per lane
+__global__ __launch_bounds__(256) void k_gray1(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ pyr, int W, int H,
+                                               int pitch, unsigned slab)
+{
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if(px >= W * H)
+        return;
+    const size_t frame = blockIdx.y;
+    const uint8_t* src = bgr + frame * (size_t)W * H * 3 + (size_t)px * 3;
+    const int y = px / W, x = px - y * W;
+    pyr[frame * slab + (size_t)y * pitch + x] = (uint8_t)gray_px(src[0], src[1], src[2]);
+}
+
+void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int n_frames, hipStream_t s)
+{
+    const LevelGeom& l0 = g.lv[0];
+    if((g.W & 3) == 0)
+    {
+        const int n_quads = (g.W * g.H) >> 2;
+        dim3 grid((n_quads + 255) / 256, n_frames);
+        hipLaunchKernelGGL(k_gray4, grid, dim3(256), 0, s, d_bgr, d_pyr + l0.offset, g.W, g.H, l0.pitch, g.slab);
+    }
+    else
+    {
+        dim3 grid((g.W * g.H + 255) / 256, n_frames);
+        hipLaunchKernelGGL(k_gray1, grid, dim3(256), 0, s, d_bgr, d_pyr + l0.offset, g.W, g.H, l0.pitch, g.slab);
+    }
+}
+
+// One lane produces 4 horizontally adjacent destination pixels (one dword store).
+// coef words: low 16 bits = weight of S[ofs], high 16 bits = weight of S[ofs+1] (both <= 2048).
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned slab, int src_off, int sw, int sh,
+                                                int spitch, int dst_off, int dw, int dh, int dpitch,
+                                                const int32_t* __restrict__ xofs, const uint32_t* __restrict__ xcoef,
+                                                const int32_t* __restrict__ yofs, const uint32_t* __restrict__ ycoef)
+{
+    const int qx = blockIdx.x * 64 + threadIdx.x;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    if(dy >= dh || (qx << 2) >= dw)
+        return;
+    const size_t frame = blockIdx.z;
+    const uint8_t* src = pyr + frame * slab + src_off;
+    uint8_t* dst = pyr + frame * slab + dst_off;
+
+    int sy0 = yofs[dy], sy1 = sy0 + 1;
+    sy0 = max(0, min(sy0, sh - 1)); // resizeGeneric_Invoker clips the row index, not the weight
+    sy1 = max(0, min(sy1, sh - 1));
+    const uint32_t yc = ycoef[dy];
+    const int b0 = (int)(yc & 0xFFFF), b1 = (int)(yc >> 16);
+    const uint8_t* S0 = src + (size_t)sy0 * spitch;
+    const uint8_t* S1 = src + (size_t)sy1 * spitch;
+
+    uint32_t out = 0;
+#pragma unroll
+    for(int k = 0; k < 4; ++k)
+    {
+        const int dx = min((qx << 2) + k, dw - 1); // pad lanes recompute the last pixel; pad bytes are never read
+        const int sx = xofs[dx];
+        const int sx1 = min(sx + 1, sw - 1);
+        const uint32_t xc = xcoef[dx];
+        const int a0 = (int)(xc & 0xFFFF), a1 = (int)(xc >> 16);
+        const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+        const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 0xFF) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + (qx << 2)) = out;
+}
+
+void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,
+                   const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s)
+{
+    const LevelGeom& src = g.lv[level - 1];
+    const LevelGeom& dst = g.lv[level];
+    const int quads = (dst.w + 3) / 4;
+    dim3 grid((quads + 63) / 64, (dst.h + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, s, d_pyr, g.slab, src.offset, src.w, src.h, src.pitch, dst.offset,
+                       dst.w, dst.h, dst.pitch, d_xofs, d_xcoef, d_yofs, d_ycoef);
+}
+
+} // namespace mslam

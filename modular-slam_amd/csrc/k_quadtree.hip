@@ -1,0 +1,364 @@
+// k_quadtree.hip — quadtree keypoint selection, one workgroup per (level, frame).
+//
+// Replaces distribute_keypoints_via_tree + initialize_nodes + orb_extractor_node::divide_node +
+// assign_child_nodes + find_keypoints_with_max_response (reference distributed_cv_feature.cpp:981-1155,
+// :306-355).  The reference walks a std::list sequentially; what it computes is order-sensitive
+// (children are push_front'ed, the loop stops when a pass leaves the list size unchanged, and the
+// surviving keypoints come out in list order).  This kernel reproduces that order in parallel:
+//
+//   list order after one pass = [ children of the LAST divided node (reversed) ... children of the
+//   FIRST divided node (reversed) ] ++ [ undivided nodes in their old order ]
+//
+// so with D_i = number of non-empty children created by divided nodes before node i, U_i = number of
+// undivided nodes before i and T = total children, child rank r of node i lands at T-1-(D_i+r) and an
+// undivided node at T+U_i: two workgroup-wide exclusive scans per pass.  Keypoints never move; each
+// carries the list position of its node.  The per-leaf winner ("first maximum", :1142-1149) is an
+// atomicMax over (score, -original index).
+#include "common.hpp"
+
+namespace mslam
+{
+
+constexpr int QT = 512;           // threads per workgroup
+constexpr int kLdsNodes = 2048;   // child counters live in LDS while the list is this short
+constexpr int kMaxCellsPerLevel = 2048;
+constexpr int kMaxInitNodes = 64;
+constexpr int kMaxPasses = 40;
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+struct Scan
+{
+    uint32_t wsum[QT / 64];
+};
+
+// exclusive scan of one value per thread across the workgroup; returns the exclusive prefix, `total`
+// receives the workgroup sum.  Two barriers; `s` may be reused right after return.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Scan& s, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for(int o = 1; o < 64; o <<= 1)
+    {
+        const uint32_t t = __shfl_up(inc, o);
+        if(lane >= o)
+            inc += t;
+    }
+    if(lane == 63)
+        s.wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for(int w = 0; w < QT / 64; ++w)
+    {
+        const uint32_t x = s.wsum[w];
+        if(w < wave)
+            base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ uint32_t ld_atomic(const uint32_t* p)
+{
+    // values produced by atomics must not be served from a stale L1 line
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void unpack_node(uint2 b, int& bx, int& by, int& ex, int& ey)
+{
+    bx = (int)(b.x & 0xFFFF), by = (int)(b.x >> 16), ex = (int)(b.y & 0xFFFF), ey = (int)(b.y >> 16);
+}
+__device__ __forceinline__ uint2 pack_node(int bx, int by, int ex, int ey)
+{
+    return make_uint2((uint32_t)bx | ((uint32_t)by << 16), (uint32_t)ex | ((uint32_t)ey << 16));
+}
+
+__global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
+{
+    __shared__ Scan scan;
+    __shared__ uint32_t cell_off[kMaxCellsPerLevel + 1];
+    __shared__ uint32_t lds_cc[kLdsNodes * 4];
+    __shared__ uint32_t init_cnt[kMaxInitNodes];
+    __shared__ uint32_t init_pos[kMaxInitNodes];
+    __shared__ uint32_t sh_n;
+
+    const int level = blockIdx.x;
+    const size_t frame = blockIdx.y;
+    const LevelGeom& lv = g.lv[level];
+    const int tid = threadIdx.x;
+    const size_t slot = frame * g.n_levels + level;
+    const size_t cap = (size_t)a.cand_cap;
+    uint32_t* cand = a.cand + slot * cap;
+    uint32_t* sel = a.sel + slot * cap;
+    uint32_t* kp_node = a.kp_node + slot * cap;
+    uint2* nodes = a.nodes_a + slot * cap;
+    uint2* nodes2 = a.nodes_b + slot * cap;
+    uint32_t* ncnt = a.ncnt_a + slot * cap;
+    uint32_t* ncnt2 = a.ncnt_b + slot * cap;
+    uint32_t* g_cc = a.child_cnt + slot * cap * 4;
+    uint32_t* ninfo = a.ninfo + slot * cap;
+    uint32_t* nbase = a.best + slot * cap; // doubles as "new base position" during passes
+
+    // ---- 0. gather this level's candidates in the reference's order: cells row-major, then the
+    //         row-major order inside each cell (:878-951)
+    const int n_cells = lv.n_cells;
+    const uint32_t* ccnt = a.cell_cnt + frame * g.n_cells + lv.cell_base;
+    uint32_t running = 0;
+    for(int base = 0; base < n_cells; base += QT)
+    {
+        const int i = base + tid;
+        const uint32_t v = i < n_cells ? ccnt[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, scan, tot);
+        if(i < n_cells)
+            cell_off[i] = running + ex;
+        running += tot;
+    }
+    if(tid == 0)
+        cell_off[n_cells] = running;
+    __syncthreads();
+    uint32_t N = running;
+    if(N > (uint32_t)a.cand_cap)
+    {
+        if(tid == 0)
+        {
+            atomicOr(a.flags, kFlagCandOverflow);
+            a.cand_cnt[slot] = 0;
+            a.sel_cnt[slot] = 0;
+        }
+        return;
+    }
+    if(tid == 0)
+        a.cand_cnt[slot] = N;
+    if(N == 0)
+    {
+        if(tid == 0)
+            a.sel_cnt[slot] = 0;
+        return;
+    }
+    const uint32_t* ckp = a.cell_kp + (frame * g.n_cells + lv.cell_base) * (size_t)kCellCap;
+    for(uint32_t j = tid; j < N; j += QT)
+    {
+        int lo = 0, hi = n_cells - 1; // last cell with cell_off <= j
+        while(lo < hi)
+        {
+            const int mid = (lo + hi + 1) >> 1;
+            if(cell_off[mid] <= j)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        cand[j] = ckp[(size_t)lo * kCellCap + (j - cell_off[lo])];
+    }
+
+    // ---- 1. initial nodes (:1025-1105)
+    const int n_init = lv.nxg * lv.nyg;
+    if(tid < kMaxInitNodes)
+        init_cnt[tid] = 0;
+    __syncthreads();
+    for(uint32_t k = tid; k < N; k += QT)
+    {
+        const uint32_t p = cand[k];
+        const unsigned ix = (unsigned)((double)(float)kp_x(p) / lv.delta_x);
+        const unsigned iy = (unsigned)((double)(float)kp_y(p) / lv.delta_y);
+        const unsigned idx = ix + iy * (unsigned)lv.nxg;
+        if(idx < (unsigned)n_init)
+        {
+            atomicAdd(&init_cnt[idx], 1u);
+            kp_node[k] = idx;
+        }
+        else
+            kp_node[k] = kNoNode;
+    }
+    __syncthreads();
+    if(tid == 0)
+    {
+        uint32_t n0 = 0;
+        for(int i = 0; i < n_init; ++i)
+        {
+            init_pos[i] = n0;
+            if(init_cnt[i] != 0)
+            {
+                const int ix = i % lv.nxg, iy = i / lv.nxg;
+                nodes[n0] = pack_node((int)(lv.delta_x * ix), (int)(lv.delta_y * iy), (int)(lv.delta_x * (ix + 1)),
+                                      (int)(lv.delta_y * (iy + 1)));
+                ncnt[n0] = init_cnt[i];
+                ++n0;
+            }
+        }
+        sh_n = n0;
+    }
+    __syncthreads();
+    for(uint32_t k = tid; k < N; k += QT)
+    {
+        const uint32_t idx = kp_node[k];
+        if(idx != kNoNode)
+            kp_node[k] = init_pos[idx];
+    }
+    uint32_t n = sh_n;
+    __syncthreads();
+
+    // ---- 2. subdivision passes (:992-1020)
+    const float sf = lv.scale;
+    const float min_size_f = (float)a.min_size;
+    bool converged = false;
+    for(int pass = 0; pass < kMaxPasses && n > 0; ++pass)
+    {
+        uint32_t* cc = n <= (uint32_t)kLdsNodes ? lds_cc : g_cc;
+        // a. which nodes divide (:1002)
+        for(uint32_t pos = tid; pos < n; pos += QT)
+        {
+            int bx, by, ex, ey;
+            unpack_node(nodes[pos], bx, by, ex, ey);
+            const unsigned area = (unsigned)((ex - bx) * (ey - by));
+            const bool keep = ncnt[pos] == 1u || __fmul_rn(__fmul_rn((float)area, sf), sf) <= min_size_f;
+            ninfo[pos] = keep ? 0u : 1u;
+            if(!keep)
+            {
+                cc[4 * pos + 0] = 0;
+                cc[4 * pos + 1] = 0;
+                cc[4 * pos + 2] = 0;
+                cc[4 * pos + 3] = 0;
+            }
+        }
+        __syncthreads();
+        // b. count keypoints per child (:340-352)
+        for(uint32_t k = tid; k < N; k += QT)
+        {
+            const uint32_t pos = kp_node[k];
+            if(pos == kNoNode || !(ninfo[pos] & 1u))
+                continue;
+            int bx, by, ex, ey;
+            unpack_node(nodes[pos], bx, by, ex, ey);
+            const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1); // cvCeil(d/2.0)
+            const uint32_t p = cand[k];
+            const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
+            atomicAdd(&cc[4 * pos + c], 1u);
+        }
+        __syncthreads();
+        // c. list positions after this pass
+        uint32_t D = 0, U = 0;
+        for(uint32_t base = 0; base < n; base += QT)
+        {
+            const uint32_t pos = base + tid;
+            uint32_t nchild = 0, und = 0, mask = 0, div = 0;
+            if(pos < n)
+            {
+                div = ninfo[pos] & 1u;
+                if(div)
+                {
+                    mask = (ld_atomic(&cc[4 * pos + 0]) ? 1u : 0u) | (ld_atomic(&cc[4 * pos + 1]) ? 2u : 0u) |
+                           (ld_atomic(&cc[4 * pos + 2]) ? 4u : 0u) | (ld_atomic(&cc[4 * pos + 3]) ? 8u : 0u);
+                    nchild = (uint32_t)__popc(mask);
+                }
+                else
+                    und = 1;
+            }
+            uint32_t totD, totU;
+            const uint32_t exD = block_excl_scan(nchild, scan, totD);
+            const uint32_t exU = block_excl_scan(und, scan, totU);
+            if(pos < n)
+            {
+                ninfo[pos] = div | (mask << 1);
+                nbase[pos] = div ? D + exD : U + exU;
+            }
+            D += totD;
+            U += totU;
+        }
+        const uint32_t T = D;
+        __syncthreads();
+        // d. materialise the new list
+        for(uint32_t pos = tid; pos < n; pos += QT)
+        {
+            const uint32_t info = ninfo[pos];
+            if(info & 1u)
+            {
+                int bx, by, ex, ey;
+                unpack_node(nodes[pos], bx, by, ex, ey);
+                const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
+                const uint32_t first = T - 1 - nbase[pos];
+                const uint32_t mask = info >> 1;
+                uint32_t r = 0;
+                if(mask & 1u) { nodes2[first - r] = pack_node(bx, by, cx, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 0]); ++r; }
+                if(mask & 2u) { nodes2[first - r] = pack_node(cx, by, ex, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 1]); ++r; }
+                if(mask & 4u) { nodes2[first - r] = pack_node(bx, cy, cx, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 2]); ++r; }
+                if(mask & 8u) { nodes2[first - r] = pack_node(cx, cy, ex, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 3]); ++r; }
+                nbase[pos] = first;
+            }
+            else
+            {
+                const uint32_t np = T + nbase[pos];
+                nodes2[np] = nodes[pos];
+                ncnt2[np] = ncnt[pos];
+                nbase[pos] = np;
+            }
+        }
+        __syncthreads();
+        // e. re-point the keypoints
+        for(uint32_t k = tid; k < N; k += QT)
+        {
+            const uint32_t pos = kp_node[k];
+            if(pos == kNoNode)
+                continue;
+            const uint32_t info = ninfo[pos];
+            uint32_t np = nbase[pos];
+            if(info & 1u)
+            {
+                int bx, by, ex, ey;
+                unpack_node(nodes[pos], bx, by, ex, ey);
+                const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
+                const uint32_t p = cand[k];
+                const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
+                np -= (uint32_t)__popc((info >> 1) & ((1u << c) - 1u));
+            }
+            kp_node[k] = np;
+        }
+        __syncthreads();
+        {
+            uint2* t = nodes; nodes = nodes2; nodes2 = t;
+            uint32_t* u = ncnt; ncnt = ncnt2; ncnt2 = u;
+        }
+        const uint32_t n2 = T + U;
+        const bool same = n2 == n; // :1016-1019 — the pass's effects stay even when it is the last
+        n = n2;
+        if(same)
+        {
+            converged = true;
+            break;
+        }
+    }
+    if(!converged && n > 0 && tid == 0)
+        atomicOr(a.flags, kFlagQuadNoConverge);
+
+    // ---- 3. winner per node, emitted in list order (:1128-1155)
+    uint32_t* best = nbase;
+    for(uint32_t pos = tid; pos < n; pos += QT)
+        best[pos] = 0;
+    __syncthreads();
+    for(uint32_t k = tid; k < N; k += QT)
+    {
+        const uint32_t pos = kp_node[k];
+        if(pos == kNoNode)
+            continue;
+        atomicMax(&best[pos], ((uint32_t)kp_score(cand[k]) << 24) | (0xFFFFFFu - k));
+    }
+    __syncthreads();
+    for(uint32_t pos = tid; pos < n; pos += QT)
+    {
+        const uint32_t k = 0xFFFFFFu - (ld_atomic(&best[pos]) & 0xFFFFFFu);
+        sel[pos] = cand[k];
+    }
+    if(tid == 0)
+        a.sel_cnt[slot] = n;
+}
+
+void launch_quadtree(const Geometry& g, const QuadArgs& a, int n_frames, hipStream_t s)
+{
+    dim3 grid(g.n_levels, n_frames);
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT), 0, s, g, a);
+}
+
+} // namespace mslam

@@ -1,0 +1,170 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("xy", "desc", "octave", "angle", "response")
+
+
+def assert_same_detection(got, ref):
+    assert len(got["xy"]) == len(ref["xy"])
+    for k in KEYS:
+        assert np.array_equal(got[k], ref[k]), k
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(width=640, height=480, max_batch=4)
+    yield c
+    c.close()
+
+
+def test_stages_bundled_frame(pkg, orc, ctx, bundled_frames):
+    """pyramid, blur, FAST candidates and quadtree selection, level by level."""
+    f = bundled_frames[0]
+    ctx.detect(f)
+    p = orc.params()
+    pyr = orc.pyramid(orc.gray(f), p)
+    w, h, s = orc.level_geometry(640, 480, p)
+    gw, gh, gs = ctx.level_geometry()
+    assert (w, h) == (gw, gh) and np.array_equal(s, gs)
+    for l in range(8):
+        assert np.array_equal(ctx.debug_image(pkg.DBG_PYRAMID, 0, l), pyr[l]), "pyramid level %d" % l
+        assert np.array_equal(ctx.debug_image(pkg.DBG_BLURRED, 0, l), orc.gaussian_blur7(pyr[l])), "blur %d" % l
+        cand = orc.fast_level(pyr[l], p)
+        got = ctx.debug_keypoints(pkg.DBG_CANDIDATES, 0, l)
+        ref = np.stack([cand["x"], cand["y"], cand["response"]], 1)
+        assert np.array_equal(got, ref), "FAST candidates level %d" % l
+        sel = orc.quadtree(cand, w[l], h[l], s[l], 1000)
+        got = ctx.debug_keypoints(pkg.DBG_SELECTED, 0, l)
+        ref = np.stack([sel["x"], sel["y"], sel["response"]], 1)
+        assert np.array_equal(got, ref), "quadtree level %d" % l
+
+
+def test_detect_bundled_frames(orc, ctx, bundled_frames):
+    for f in bundled_frames:
+        assert_same_detection(ctx.detect(f), orc.detect(f, orc.params()))
+
+
+def test_detect_synthetic(orc, ctx, synth_frames):
+    for f in synth_frames[:3]:
+        assert_same_detection(ctx.detect(f), orc.detect(f, orc.params()))
+
+
+@pytest.mark.parametrize("min_area,levels", [(150, 8), (300, 3), (4000, 5)])
+def test_detect_parameters(pkg, orc, synth_frames, min_area, levels):
+    c = pkg.Context(width=640, height=480, n_levels=levels, min_node_area=min_area, max_keypoints=16384)
+    got = c.detect(synth_frames[0], max_out=16384)
+    ref = orc.detect(synth_frames[0], orc.params(n_levels=levels, min_size=min_area))
+    assert_same_detection(got, ref)
+    c.close()
+
+
+@pytest.mark.parametrize("size", [(100, 80), (333, 207), (1280, 720)])
+def test_detect_other_sizes(pkg, orc, size):
+    import synth
+    W, H = size
+    levels = 3 if W < 200 else 8
+    f = synth.make_stream(1, W, H, seed=99)[0]
+    c = pkg.Context(width=W, height=H, n_levels=levels, max_keypoints=20000, max_candidates=65536)
+    got = c.detect(f, max_out=20000)
+    ref = orc.detect(f, orc.params(n_levels=levels))
+    assert_same_detection(got, ref)
+    c.close()
+
+
+def test_detect_flat_and_noise_frames(pkg, orc, ctx):
+    flat = np.full((480, 640, 3), 128, np.uint8)
+    got = ctx.detect(flat)
+    assert len(got["xy"]) == 0 and len(orc.detect(flat, orc.params())["xy"]) == 0
+    noise = np.random.default_rng(5).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    c = pkg.Context(width=640, height=480, max_keypoints=32768, max_candidates=65536)
+    assert_same_detection(c.detect(noise, max_out=32768), orc.detect(noise, orc.params()))
+    c.close()
+
+
+def test_capacity_is_loud(pkg, synth_frames):
+    c = pkg.Context(width=640, height=480, max_keypoints=100)
+    with pytest.raises(pkg.MslamHipError) as e:
+        c.detect(synth_frames[0])
+    assert e.value.code == pkg.E_CAPACITY
+    c.close()
+
+
+def test_match_knn2_random(orc, ctx):
+    rng = np.random.default_rng(1)
+    for n_from, n_to in [(2000, 2000), (513, 257), (1, 5), (2, 3), (300, 1)]:
+        f = rng.integers(0, 256, (n_from, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (n_to, 32), dtype=np.uint8)
+        got = ctx.match_knn2(f, t)
+        ref = orc.match_knn2_raw(f, t)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g, r)
+
+
+def test_match_ties_and_ratio(orc, ctx):
+    """few distinct descriptors => many equal distances: the lower train index must rank first."""
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 256, (7, 32), dtype=np.uint8)
+    f = base[rng.integers(0, 7, 700)]
+    t = base[rng.integers(0, 7, 300)].copy()
+    t[::3, 0] ^= 1
+    for g, r in zip(ctx.match_knn2(f, t), orc.match_knn2_raw(f, t)):
+        assert np.array_equal(g, r)
+    for ratio in (0.7, 0.5, 1.0, 0.0):
+        gf, gt = ctx.match(f, t, ratio)
+        rf, rt = orc.match(f, t, ratio)
+        assert np.array_equal(gf, rf) and np.array_equal(gt, rt)
+
+
+def test_match_detected_frames(orc, ctx, bundled_frames):
+    a = orc.detect(bundled_frames[0], orc.params())
+    b = orc.detect(bundled_frames[1], orc.params())
+    gf, gt = ctx.match(b["desc"], a["desc"])
+    rf, rt = orc.match(b["desc"], a["desc"])
+    assert len(rf) > 100
+    assert np.array_equal(gf, rf) and np.array_equal(gt, rt)
+
+
+def test_match_degenerate(ctx):
+    d = np.zeros((5, 32), np.uint8)
+    assert len(ctx.match(d[:1], d)[0]) == 0      # n_from < 2: reference UB, defined as no matches
+    assert len(ctx.match(d, d[:0])[0]) == 0      # empty query set
+    assert len(ctx.match(d[:0], d)[0]) == 0
+
+
+def test_batch_device_path(pkg, orc, synth_frames):
+    """detect_batch_dev + match_batch_dev on HBM-resident frames, including the chain across batches."""
+    import torch
+    frames = synth_frames[:6]
+    dev = torch.from_numpy(frames).cuda()
+    c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=4096)
+    refs = [orc.detect(f, orc.params()) for f in frames]
+    K = 4096
+    for b in range(2):
+        c.detect_batch_dev(dev[3 * b:].data_ptr(), 3)
+        c.match_batch_dev(0.7, True)
+        c.sync()
+        v = c.batch_view()
+        assert v.n_frames == 3 and v.capacity == K
+
+        rd = pkg.read_device
+        cnt = rd(v.count, (3,), np.int32)
+        desc = rd(v.desc, (3, K, 32), np.uint8)
+        xy = rd(v.xy, (3, K, 2), np.float32)
+        mc = rd(v.match_count, (3,), np.int32)
+        mf = rd(v.match_from, (3, K), np.int32)
+        mt = rd(v.match_to, (3, K), np.int32)
+        for i in range(3):
+            r = refs[3 * b + i]
+            assert cnt[i] == len(r["xy"])
+            assert np.array_equal(desc[i, :cnt[i]], r["desc"]) and np.array_equal(xy[i, :cnt[i]], r["xy"])
+            t = 3 * b + i
+            if t == 0:
+                assert mc[i] == 0
+            else:
+                rf, rt = orc.match(refs[t]["desc"], refs[t - 1]["desc"])
+                assert mc[i] == len(rf)
+                assert np.array_equal(mf[i, :mc[i]], rf) and np.array_equal(mt[i, :mc[i]], rt)
+    c.close()
