@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — ORB extract + BF-Hamming match throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of HBM-resident synthetic frames:
+detect (gray -> pyramid -> FAST cells -> quadtree -> blur -> orientation + rBRIEF) followed by the
+knn-2 Hamming match of every frame against its predecessor (chained across batches), exactly the
+call order of RgbdFeatureFrontend (rgbd_feature_frontend.cpp:187,237).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run (one rank per GPU): every rank runs its own stream
+(seed 1234 + 100*rank), no data-path collective is needed for extract+match ("weak" scaling);
+timing is barrier + synchronize on both sides and the MAX over ranks.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the context's stream
+for the dominant kernel; `cpu_baseline` times the CPU oracle (oracle/, the restatement of the
+reference's CPU plugin) on a bounded sample of the same stream on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=100, help="frames per step")
+    ap.add_argument("--unique", type=int, default=200, help="distinct synthetic frames kept in HBM (cycled)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="frames of the stream timed on the CPU oracle")
+    return ap.parse_args()
+
+
+def stage_bytes(ctx, B, n_kp, n_cand):
+    """Algorithmic HBM bytes per LAUNCH for every stage: each input byte read once,
+    each output byte written once, for a batch of B frames with n_kp keypoints / n_cand FAST
+    candidates in total."""
+    w, h, _ = ctx.level_geometry()
+    px = [a * b for a, b in zip(w, h)]
+    P = sum(px)
+    return {
+        "gray": B * (3 * px[0] + px[0]),
+        "resize": B * sum(px[l - 1] + px[l] for l in range(1, len(px))),
+        "fast": B * P + 4 * n_cand,
+        "quadtree": 4 * n_cand + 4 * n_kp,
+        "blur": B * 2 * P,
+        "describe": B * 2 * P + 48 * n_kp,  # reads both planes around each keypoint, writes desc+xy+angle+octave+resp
+        "match_knn2": 2 * 32 * n_kp + 16 * n_kp,
+        "ratio_compact": 12 * n_kp + 8 * n_kp,
+    }
+
+
+def cpu_baseline(frames, n_sample):
+    """Oracle (= port of the reference CPU plugin) detect + match on the host cores."""
+    import __graft_entry__ as graft
+    from concurrent.futures import ThreadPoolExecutor
+    orc = graft.load_oracle()
+    orc.lib()
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    n_sample = min(n_sample, len(frames))
+    p = orc.params()
+    sample = [np.ascontiguousarray(frames[i]) for i in range(n_sample)]
+
+    # detect every frame once (parallel over frames), then match consecutive pairs (parallel over pairs):
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        dets = list(ex.map(lambda i: orc.detect(sample[i], p), range(n_sample)))
+        list(ex.map(lambda i: orc.match(dets[i]["desc"], dets[i - 1]["desc"]), range(1, n_sample)))
+    dt = time.perf_counter() - t0
+    n_kp = sum(len(d["xy"]) for d in dets)
+    return {"value": n_kp / dt, "unit": "keypoints/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same synthetic 640x480 stream, detect + knn-2 match vs previous frame, "
+                      "oracle/ C restatement (scalar; OpenCV's internal SIMD is not reproduced), %d threads over frames"
+                      % (n_sample, cores)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    import synth
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+
+    B = a.batch
+    n_unique = max(B, (a.unique // B) * B)
+    frames = synth.make_stream(n_unique, a.width, a.height, seed=1234 + 100 * rank)
+    d_frames = torch.from_numpy(frames).cuda()
+    frame_bytes = a.width * a.height * 3
+
+    ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, max_keypoints=4096, max_candidates=16384,
+                      device=local)
+    n_batches = n_unique // B
+
+    def step(i):
+        off = (i % n_batches) * B
+        ctx.detect_batch_dev(d_frames.data_ptr() + off * frame_bytes, B)
+        ctx.match_batch_dev(0.7, True)
+
+    for i in range(a.warmup):
+        step(i)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    ctx.sync()  # also surfaces capacity overflows loudly
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+
+    # units processed: keypoints extracted (and matched against the previous frame) in the timed steps
+    v = ctx.batch_view()
+    counts_per_batch = []
+    cand_per_batch = []
+    for b in range(n_batches):  # untimed: count keypoints of each distinct batch once
+        ctx.detect_batch_dev(d_frames.data_ptr() + b * B * frame_bytes, B)
+        ctx.sync()
+        counts_per_batch.append(int(pkg.read_device(ctx, v.count, (B,), np.int32).sum()))
+        cand_per_batch.append(sum(len(ctx.debug_keypoints(pkg.DBG_CANDIDATES, 0, l)) for l in range(8)) * B)
+    n_kp = sum(counts_per_batch[(a.warmup + i) % n_batches] for i in range(a.steps))
+
+    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    kp_sum = torch.tensor([float(n_kp)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kp_sum, op=dist.ReduceOp.SUM)
+    dt_max, kp_total = float(t_max.item()), float(kp_sum.item())
+
+    out = None
+    if rank == 0:
+        # per-kernel timing with HIP events on the context's stream (outside the timed region)
+        ctx.set_profiling(True)
+        acc = {}
+        reps = 5
+        for i in range(reps):
+            step(i)
+            for name, ms in ctx.stage_times():
+                acc[name] = acc.get(name, 0.0) + ms / reps
+        ctx.set_profiling(False)
+        kp_b, cand_b = counts_per_batch[0], cand_per_batch[0]
+        sb = stage_bytes(ctx, B, kp_b, cand_b)
+        dom = max(acc, key=acc.get)
+        launches = 7 if dom == "resize" else 1
+        achieved = sb[dom] / (acc[dom] * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": launches, "avg_ms": round(acc[dom], 4),
+                    "algorithmic_bytes_per_launch": sb[dom] // launches,
+                    "stages_ms": {k: round(x, 4) for k, x in acc.items()},
+                    "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0}}
+        w, h, _ = ctx.level_geometry()
+        P = sum(x * y for x, y in zip(w, h))
+        extract_bytes = 3 * a.width * a.height + 2 * P + 48 * (kp_b / B)
+        out = {
+            "metric": "ORB keypoints extracted+matched /sec, 640x480 RGB-D", "value": kp_total / dt_max,
+            "unit": "keypoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "cfg2: synthetic %dx%d stream, 8-level ORB (reference defaults 1.2/20/7/min-area 1000), "
+                                   "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame" % (a.width, a.height),
+                       "frames_per_step": B, "frames_per_gpu": a.steps * B, "distinct_frames": n_unique,
+                       "keypoints_per_frame": round(kp_b / B, 1), "fast_candidates_per_frame": round(cand_b / B, 1),
+                       "frames_per_s": a.steps * B * world / dt_max,
+                       "extract_algorithmic_GBps_whole_job": extract_bytes * a.steps * B * world / dt_max / 1e9},
+            "roofline": roofline,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames, a.cpu_sample)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,9 @@ int mslam_hip_level_geometry(mslam_hip_ctx* ctx, int* widths, int* heights, floa
 int mslam_hip_debug_read(mslam_hip_ctx* ctx, int what, int frame, int level, void* dst, size_t dst_bytes,
                          size_t* n_items);
 
+/* Synchronise the context's stream, then copy `bytes` from a device pointer (e.g. out of a view) to host memory. */
+int mslam_hip_copy_to_host(mslam_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
 /* Per-stage device time (ms) of the last mslam_hip_detect_batch_dev / match_batch_dev when profiling
  * is enabled (HIP events on the context's stream).  names/ms hold up to cap entries. */
 int mslam_hip_set_profiling(mslam_hip_ctx* ctx, int enable);

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "mslam_hip_bow_load", "mslam_hip_bow_info", "mslam_hip_bow_words", "mslam_hip_bow_transform",
     "mslam_hip_bow_score", "mslam_hip_bow_db_add", "mslam_hip_bow_db_query", "mslam_hip_bow_db_clear",
     "mslam_hip_bow_batch_dev", "mslam_hip_get_bow_view", "mslam_hip_level_geometry", "mslam_hip_debug_read",
-    "mslam_hip_set_profiling", "mslam_hip_get_stage_times",
+    "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host",
 ]
 
 
@@ -77,6 +77,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MslamHipError(E_RUNTIME, "libmslam_hip.so is not built (run __graft_entry__.build()); "
                                            "the product path has no CPU fallback")
+        # PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7).  Two HIP runtimes in one
+        # process cannot both open the GPU, so when torch is available load it FIRST: our NEEDED
+        # libamdhip64.so.7 then binds to the runtime torch already mapped.  Without torch (pure C/C++
+        # hosts) the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.mslam_hip_last_error.restype = C.c_char_p
         L.mslam_hip_last_error.argtypes = [C.c_void_p]
@@ -369,22 +377,10 @@ class HipLoopDetector:
         return self._last
 
 
-# ---- small HIP runtime helpers for harness code (bench / tests): raw device <-> host copies ---------
-_hiprt = None
-
-
-def _hip():
-    global _hiprt
-    if _hiprt is None:
-        _hiprt = C.CDLL("libamdhip64.so")
-    return _hiprt
-
-
-def read_device(ptr, shape, dtype):
-    """Copy a context-owned device array (raw pointer from a *_view struct) to a numpy array."""
+# ---- harness helper (bench / tests): copy a context-owned device array to the host ------------------
+def read_device(ctx, ptr, shape, dtype):
+    """Copy a device array (raw pointer from a *_view struct) into a new numpy array."""
     out = np.empty(shape, dtype)
     if out.nbytes:
-        rc = _hip().hipMemcpy(_p(out), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2)  # hipMemcpyDeviceToHost
-        if rc != 0:
-            raise MslamHipError(E_RUNTIME, "hipMemcpy D2H failed (%d)" % rc)
+        ctx._chk(ctx.L.mslam_hip_copy_to_host(ctx._h, _p(out), C.c_void_p(ptr), C.c_size_t(out.nbytes)))
     return out

@@ -828,6 +828,17 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
     return fail(c, MSLAM_HIP_E_INVALID, "debug_read: unknown item");
 }
 
+int mslam_hip_copy_to_host(mslam_hip_ctx* c, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(!dst_host || !src_dev)
+        return fail(c, MSLAM_HIP_E_INVALID, "copy_to_host: null pointer");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return MSLAM_HIP_OK;
+}
+
 int mslam_hip_set_profiling(mslam_hip_ctx* c, int enable)
 {
     if(!c)

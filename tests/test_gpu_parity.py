@@ -149,7 +149,8 @@ def test_batch_device_path(pkg, orc, synth_frames):
         v = c.batch_view()
         assert v.n_frames == 3 and v.capacity == K
 
-        rd = pkg.read_device
+        def rd(ptr, shape, dt):
+            return pkg.read_device(c, ptr, shape, dt)
         cnt = rd(v.count, (3,), np.int32)
         desc = rd(v.desc, (3, K, 32), np.uint8)
         xy = rd(v.xy, (3, K, 2), np.float32)
