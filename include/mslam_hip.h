@@ -115,6 +115,24 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* ctx, double ratio, int chain_previo
  * loop_detection.hpp:10-15): DBoW3::Vocabulary::transform and Database add/query with L1 scoring.
  * `blob` is a DBoW3 binary vocabulary stream (Vocabulary::toStream/fromStream,
  * conan_recipes/dbow3/dbow3.patch:2252-2355,2544-2651), uncompressed. */
+enum /* DBoW3 WeightingType / ScoringType as stored in the vocabulary stream */
+{
+    MSLAM_BOW_TF_IDF = 0,
+    MSLAM_BOW_TF = 1,
+    MSLAM_BOW_IDF = 2,
+    MSLAM_BOW_BINARY = 3
+};
+enum
+{
+    MSLAM_BOW_L1_NORM = 0,
+    MSLAM_BOW_L2_NORM = 1,
+    MSLAM_BOW_CHI_SQUARE = 2,
+    MSLAM_BOW_KL = 3,
+    MSLAM_BOW_BHATTACHARYYA = 4,
+    MSLAM_BOW_DOT_PRODUCT = 5
+};
+/* Only L1_NORM scoring vocabularies are accepted (the ORB vocabularies DBoW3 ships are TF_IDF / L1_NORM).
+ * The database keeps the 64 most recent entries (a ring); older entries are dropped. */
 int mslam_hip_bow_load(mslam_hip_ctx* ctx, const void* blob, size_t size);
 int mslam_hip_bow_info(mslam_hip_ctx* ctx, int* k, int* L, int* n_nodes, int* n_words, int* scoring,
                        int* weighting);

@@ -1,34 +1,844 @@
-// k_bow.hip — DBoW3 bag-of-words: vocabulary tree descent, BoW vectors, L1 scoring, database.
-// (first slice: entry points exist and fail loudly until a vocabulary is loaded)
+// k_bow.hip — DBoW3 bag of words on the GPU: vocabulary-tree descent, BoW vectors, L1 scoring, database.
+//
+// Replaces what the reference wires OrbRelocalizer for (orb_relocalizer.cpp:26-50) and the DBoW3
+// library code behind it (rmsalinas/DBow3 master; only Vocabulary.cpp/.h text is in the reference tree,
+// inside conan_recipes/dbow3/dbow3.patch):
+//   Vocabulary::fromStream                              dbow3.patch:2544-2651   (host parser below)
+//   Vocabulary::transform(feature, word_id, weight)     dbow3.patch:1760-1860   (k_bow_descend)
+//   Vocabulary::transform(features, BowVector)          dbow3.patch:1432-1530   (k_bow_vector)
+//   BowVector::addWeight / addIfNotExist / normalize, L1Scoring::score, Database::add / queryL1
+//   (DBoW3 sources not in the tree; restated from the published algorithm)               (k_bow_vector, k_bow_score)
+//
+// Bit-exactness notes.  Word assignment is integer-only (256-bit Hamming argmin, strict `<` so the
+// first child wins ties).  BoW values and scores are f64 and every sum is evaluated in the order the
+// reference's std::map iteration / feature loop fixes: a word hit c times is w+w+...+w accumulated
+// sequentially, the L1 norm is a sequential sum over ascending word ids, a score is a sequential sum
+// over the common words in ascending order.  Those chains are short (<= keypoints per frame) and run
+// one per frame / per (frame, entry) pair, so thousands of them run in parallel across the batch.
 #include "context.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 
 namespace mslam
 {
+
+constexpr int kBowGroup = 16; // lanes cooperating on one descriptor: one child each, <= 16 per step
+
 struct BowState
 {
-    int dummy;
+    int k = 0, L = 0, scoring = 0, weighting = 0;
+    uint32_t n_nodes = 0, n_words = 0;
+    int max_children = 0;
+    // device tree, indexed by "slot": the children of a node occupy consecutive slots in stream order
+    uint4* d_desc = nullptr;        // [n_nodes][2]
+    uint32_t* d_first = nullptr;    // first child slot (0 = leaf)
+    uint32_t* d_nchild = nullptr;
+    uint32_t* d_word = nullptr;     // word id of a leaf
+    double* d_weight = nullptr;
+    // per-feature scratch for a batch
+    uint32_t* d_fword = nullptr;    // [B][cap]
+    double* d_fweight = nullptr;    // [B][cap]
+    // BoW vectors of the current batch (slot B = the host-pointer query)
+    uint32_t* d_bwords = nullptr;   // [B+1][cap]
+    double* d_bvalues = nullptr;    // [B+1][cap]
+    int32_t* d_bn = nullptr;        // [B+1]
+    // database ring: R live entries + B in flight
+    int R = 64, RP = 0;
+    uint32_t* d_rwords = nullptr;   // [RP][cap]
+    double* d_rvalues = nullptr;
+    int32_t* d_rn = nullptr;        // [RP]
+    long long next_id = 0;
+    // scoring outputs
+    double* d_scores = nullptr;     // [B+1][R]   score against entry (id_t - 1 - j), -1 when absent / no common word
+    int32_t* d_best_entry = nullptr; // [B+1]
+    double* d_best_score = nullptr;
+    uint8_t* d_hdesc = nullptr;     // host-pointer query descriptors [cap][32]
+    int cap = 0, B = 0;
 };
-void bow_destroy(BowState* b) { delete b; }
-int bow_batch(mslam_hip_ctx* c, int) { c->err = "no vocabulary loaded"; return MSLAM_HIP_E_NO_VOCABULARY; }
+
+static void bow_free(BowState* b)
+{
+    void* bufs[] = {b->d_desc,   b->d_first,   b->d_nchild, b->d_word,   b->d_weight,     b->d_fword,      b->d_fweight,
+                    b->d_bwords, b->d_bvalues, b->d_bn,     b->d_rwords, b->d_rvalues,    b->d_rn,         b->d_scores,
+                    b->d_best_entry, b->d_best_score, b->d_hdesc};
+    for(void* p : bufs)
+        if(p)
+            (void)hipFree(p);
+}
+void bow_destroy(BowState* b)
+{
+    if(!b)
+        return;
+    bow_free(b);
+    delete b;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------
+
+// 16 lanes walk one descriptor down the tree; lane c scores child c of the current node.
+__global__ __launch_bounds__(256) void k_bow_descend(const uint8_t* __restrict__ desc, long long desc_stride,
+                                                     const int32_t* __restrict__ counts, int n_fixed, int cap,
+                                                     const uint4* __restrict__ tdesc, const uint32_t* __restrict__ first,
+                                                     const uint32_t* __restrict__ nchild,
+                                                     const uint32_t* __restrict__ word, const double* __restrict__ weight,
+                                                     uint32_t* __restrict__ out_word, double* __restrict__ out_weight)
+{
+    const int frame = blockIdx.y;
+    const int n = min(counts ? counts[frame] : n_fixed, cap);
+    const int sub = threadIdx.x & (kBowGroup - 1);
+    const int i = (blockIdx.x * 256 + threadIdx.x) / kBowGroup;
+    if(i >= n)
+        return; // whole 16-lane group leaves together
+    const uint4* q = reinterpret_cast<const uint4*>(desc + (long long)frame * desc_stride + (size_t)i * 32);
+    const uint4 qa = q[0], qb = q[1];
+    uint32_t node = 0;
+    uint32_t nc = nchild[0];
+    while(nc != 0)
+    {
+        const uint32_t fc = first[node];
+        uint32_t best = 0xFFFFFFFFu; // (distance << 16) | child index: min == first child with the least distance
+        for(uint32_t c0 = 0; c0 < nc; c0 += kBowGroup)
+        {
+            const uint32_t c = c0 + sub;
+            if(c < nc)
+            {
+                const uint4* t = tdesc + (size_t)(fc + c) * 2;
+                const uint4 ta = t[0], tb = t[1];
+                const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                   __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                best = min(best, (d << 16) | c);
+            }
+        }
+#pragma unroll
+        for(int o = kBowGroup / 2; o > 0; o >>= 1)
+            best = min(best, (uint32_t)__shfl_xor((int)best, o, kBowGroup));
+        node = fc + (best & 0xFFFFu);
+        nc = nchild[node];
+    }
+    if(sub == 0)
+    {
+        const size_t o = (size_t)frame * cap + i;
+        out_word[o] = word[node];
+        out_weight[o] = weight[node];
+    }
+}
+
+constexpr int VT = 512;
+
+// One workgroup per frame: (word, feature index) pairs -> ascending unique words with accumulated,
+// normalised values.
+__global__ __launch_bounds__(VT) void k_bow_vector(const uint32_t* __restrict__ fword, const double* __restrict__ fweight,
+                                                   const int32_t* __restrict__ counts, int n_fixed, int cap, int npow2,
+                                                   int weighting, int scoring, uint32_t* __restrict__ bwords,
+                                                   double* __restrict__ bvalues, int32_t* __restrict__ bn, int slot0)
+{
+    extern __shared__ unsigned long long keys[]; // npow2 sort keys, reused as f64 values afterwards
+    __shared__ uint32_t wsum[VT / 64];
+    __shared__ double sh_norm;
+
+    const int frame = blockIdx.x;
+    const int n = min(counts ? counts[frame] : n_fixed, cap);
+    const int tid = threadIdx.x;
+    const uint32_t* fw = fword + (size_t)frame * cap;
+    const double* fv = fweight + (size_t)frame * cap;
+    uint32_t* ow = bwords + (size_t)(slot0 + frame) * cap;
+    double* ov = bvalues + (size_t)(slot0 + frame) * cap;
+
+    for(int i = tid; i < npow2; i += VT)
+    {
+        unsigned long long key = ~0ull;
+        if(i < n && fv[i] > 0) // "not stopped" (dbow3.patch transform: if (w > 0))
+            key = ((unsigned long long)fw[i] << 32) | (uint32_t)i;
+        keys[i] = key;
+    }
+    __syncthreads();
+    // bitonic sort, ascending: by word id, then by feature index (= the order of the reference's loop)
+    for(int size = 2; size <= npow2; size <<= 1)
+        for(int stride = size >> 1; stride > 0; stride >>= 1)
+        {
+            for(int t = tid; t < (npow2 >> 1); t += VT)
+            {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if((a > b) == up)
+                {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // heads of equal-word runs -> output positions
+    uint32_t running = 0;
+    const bool tf = weighting == MSLAM_BOW_TF || weighting == MSLAM_BOW_TF_IDF;
+    for(int base = 0; base < npow2; base += VT)
+    {
+        const int i = base + tid;
+        const unsigned long long key = i < npow2 ? keys[i] : ~0ull;
+        const bool valid = key != ~0ull;
+        const bool head = valid && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != (uint32_t)(key >> 32));
+        // workgroup exclusive scan of the head flags
+        const int lane = tid & 63, wave = tid >> 6;
+        const unsigned long long bal = __ballot(head);
+        if(lane == 0)
+            wsum[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for(int w = 0; w < VT / 64; ++w)
+        {
+            if(w < wave)
+                pre += wsum[w];
+            tot += wsum[w];
+        }
+        if(head)
+        {
+            const uint32_t pos = running + pre + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            const uint32_t wid = (uint32_t)(key >> 32);
+            const double w = fv[(uint32_t)key];
+            double v = w; // addWeight: first hit inserts w, later hits += w (same word => same weight)
+            if(tf)
+                for(int j = i + 1; j < npow2 && (uint32_t)(keys[j] >> 32) == wid && keys[j] != ~0ull; ++j)
+                    v += w;
+            ow[pos] = wid;
+            ov[pos] = v;
+        }
+        running += tot;
+        __syncthreads();
+    }
+    const uint32_t m = running;
+    __syncthreads();
+    // normalisation (ScoringObject::mustNormalize): L1 for L1/CHI/KL/BHATTACHARYYA, L2 for L2, none for DOT
+    double* vals = reinterpret_cast<double*>(keys);
+    for(uint32_t i = tid; i < m; i += VT)
+        vals[i] = ov[i];
+    __syncthreads();
+    const bool must = scoring != MSLAM_BOW_DOT_PRODUCT;
+    if(tid == 0)
+    {
+        double norm = 0.0;
+        if(must)
+        {
+            if(scoring == MSLAM_BOW_L2_NORM)
+            {
+                for(uint32_t i = 0; i < m; ++i)
+                    norm += vals[i] * vals[i];
+                norm = sqrt(norm);
+            }
+            else
+                for(uint32_t i = 0; i < m; ++i)
+                    norm += fabs(vals[i]);
+        }
+        else if(tf && m > 0)
+            norm = (double)m; // "unnecessary when normalizing": divide by the number of words
+        sh_norm = norm;
+        bn[slot0 + frame] = (int32_t)m;
+    }
+    __syncthreads();
+    const double norm = sh_norm;
+    if(norm > 0.0)
+        for(uint32_t i = tid; i < m; i += VT)
+            ov[i] = vals[i] / norm;
+}
+
+// copy the batch's vectors into their database ring slots
+__global__ __launch_bounds__(256) void k_bow_commit(const uint32_t* __restrict__ bwords, const double* __restrict__ bvalues,
+                                                    const int32_t* __restrict__ bn, int cap, long long base_id, int RP,
+                                                    uint32_t* __restrict__ rwords, double* __restrict__ rvalues,
+                                                    int32_t* __restrict__ rn)
+{
+    const int t = blockIdx.x;
+    const int slot = (int)((base_id + t) % RP);
+    const int n = bn[t];
+    for(int i = threadIdx.x; i < n; i += 256)
+    {
+        rwords[(size_t)slot * cap + i] = bwords[(size_t)t * cap + i];
+        rvalues[(size_t)slot * cap + i] = bvalues[(size_t)t * cap + i];
+    }
+    if(threadIdx.x == 0)
+        rn[slot] = n;
+}
+
+// L1Scoring::score of query vector `qslot + blockIdx.y` against the window of database entries that
+// precede it.  One thread per (query, entry); the workgroup then picks the best entry.
+__global__ void k_bow_score(const uint32_t* __restrict__ bwords, const double* __restrict__ bvalues,
+                            const int32_t* __restrict__ bn, int qslot, int cap, const uint32_t* __restrict__ rwords,
+                            const double* __restrict__ rvalues, const int32_t* __restrict__ rn, long long base_id,
+                            int per_frame_id, int R, int RP, double* __restrict__ scores, int32_t* __restrict__ best_entry,
+                            double* __restrict__ best_score)
+{
+    extern __shared__ double red[]; // blockDim.x scores then ids
+    const int t = blockIdx.y;
+    const int j = threadIdx.x;
+    const long long id_t = base_id + (per_frame_id ? t : 0); // entries with id < id_t are visible
+    const long long e_id = id_t - 1 - j;
+    double score = -1.0;
+    if(j < R && e_id >= 0)
+    {
+        const int slot = (int)(e_id % RP);
+        const uint32_t* w1 = bwords + (size_t)(qslot + t) * cap;
+        const double* v1 = bvalues + (size_t)(qslot + t) * cap;
+        const int n1 = bn[qslot + t];
+        const uint32_t* w2 = rwords + (size_t)slot * cap;
+        const double* v2 = rvalues + (size_t)slot * cap;
+        const int n2 = rn[slot];
+        int a = 0, b = 0;
+        double s = 0;
+        bool common = false;
+        while(a < n1 && b < n2)
+        {
+            const uint32_t x = w1[a], y = w2[b];
+            if(x == y)
+            {
+                const double vi = v1[a], wi = v2[b];
+                s += fabs(vi - wi) - fabs(vi) - fabs(wi);
+                common = true;
+                ++a, ++b;
+            }
+            else if(x < y)
+                ++a;
+            else
+                ++b;
+        }
+        if(common) // Database::queryL1 only reports entries sharing a word with the query
+            score = -s / 2.0;
+    }
+    if(j < R)
+        scores[(size_t)(qslot + t) * R + j] = score;
+    // best = highest score, ties to the lower entry id (= the higher j)
+    double* rs = red;
+    long long* rid = reinterpret_cast<long long*>(red + blockDim.x);
+    rs[j] = score;
+    rid[j] = score >= 0 ? e_id : -1;
+    __syncthreads();
+    for(int o = blockDim.x >> 1; o > 0; o >>= 1)
+    {
+        if(j < o)
+        {
+            const double s2 = rs[j + o];
+            const long long i2 = rid[j + o];
+            if(i2 >= 0 && (rid[j] < 0 || s2 > rs[j] || (s2 == rs[j] && i2 < rid[j])))
+            {
+                rs[j] = s2;
+                rid[j] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if(j == 0)
+    {
+        best_entry[qslot + t] = (int32_t)rid[0];
+        best_score[qslot + t] = rid[0] >= 0 ? rs[0] : 0.0;
+    }
+}
+
+// L1Scoring::score of two explicit vectors (host-pointer entry point)
+__global__ void k_bow_score_pair(const uint32_t* __restrict__ w1, const double* __restrict__ v1, int n1,
+                                 const uint32_t* __restrict__ w2, const double* __restrict__ v2, int n2,
+                                 double* __restrict__ out)
+{
+    int a = 0, b = 0;
+    double s = 0;
+    while(a < n1 && b < n2)
+    {
+        const uint32_t x = w1[a], y = w2[b];
+        if(x == y)
+        {
+            const double vi = v1[a], wi = v2[b];
+            s += fabs(vi - wi) - fabs(vi) - fabs(wi);
+            ++a, ++b;
+        }
+        else if(x < y)
+            ++a;
+        else
+            ++b;
+    }
+    *out = -s / 2.0;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+#define BHIPCHK(c, call)                                                                                               \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (call);                                                                                        \
+        if(e_ != hipSuccess)                                                                                           \
+        {                                                                                                              \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                              \
+            return MSLAM_HIP_E_RUNTIME;                                                                                \
+        }                                                                                                              \
+    } while(0)
+
+static int bfail(mslam_hip_ctx* c, int code, const char* msg)
+{
+    c->err = msg;
+    return code;
+}
+
+template <typename T>
+static hipError_t bmalloc(T*& p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(T));
+}
+
+static int pow2_at_least(int n)
+{
+    int p = 64;
+    while(p < n)
+        p <<= 1;
+    return p;
+}
+
+struct Reader
+{
+    const uint8_t* p;
+    size_t size, pos = 0;
+    bool ok = true;
+    template <typename T>
+    T get()
+    {
+        T v{};
+        if(pos + sizeof(T) > size)
+        {
+            ok = false;
+            return v;
+        }
+        std::memcpy(&v, p + pos, sizeof(T));
+        pos += sizeof(T);
+        return v;
+    }
+};
+
+static int bow_load_impl(mslam_hip_ctx* c, const void* blob, size_t size)
+{
+    // Vocabulary::fromStream (dbow3.patch:2544-2651)
+    Reader r{static_cast<const uint8_t*>(blob), size};
+    if(r.get<uint64_t>() != 88877711233ull)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: bad magic (not a DBoW3 binary vocabulary)");
+    const uint8_t compressed = r.get<uint8_t>();
+    const uint32_t n_nodes = r.get<uint32_t>();
+    if(!r.ok || n_nodes == 0)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: empty vocabulary");
+    if(compressed)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: QuickLZ-compressed streams are not supported; save with compressed=false");
+    const int k = r.get<int32_t>(), L = r.get<int32_t>(), scoring = r.get<int32_t>(), weighting = r.get<int32_t>();
+    if(!r.ok || k < 1 || weighting < 0 || weighting > 3 || scoring < 0 || scoring > 5)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: bad header");
+    if(scoring != MSLAM_BOW_L1_NORM)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: only L1_NORM scoring vocabularies are supported");
+    std::vector<uint32_t> parent(n_nodes, 0), order(n_nodes, 0), nchild(n_nodes, 0), word(n_nodes, 0);
+    std::vector<double> weight(n_nodes, 0.0);
+    std::vector<uint8_t> desc((size_t)n_nodes * 32, 0);
+    for(uint32_t i = 1; i < n_nodes; ++i)
+    {
+        const uint32_t nid = r.get<uint32_t>(), par = r.get<uint32_t>();
+        const double w = r.get<double>();
+        const int32_t cols = r.get<int32_t>(), rows = r.get<int32_t>(), type = r.get<int32_t>(); // DescManip::fromStream
+        if(!r.ok || nid >= n_nodes || par >= n_nodes || cols != 32 || rows != 1 || type != 0 || r.pos + 32 > size)
+            return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: bad node record (only 32-byte CV_8U descriptors are supported)");
+        parent[nid] = par;
+        weight[nid] = w;
+        std::memcpy(&desc[(size_t)nid * 32], r.p + r.pos, 32);
+        r.pos += 32;
+        order[i] = nid;
+        nchild[par]++;
+    }
+    const uint32_t n_words = r.get<uint32_t>();
+    if(!r.ok)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: truncated stream");
+    for(uint32_t i = 0; i < n_words; ++i)
+    {
+        const uint32_t wid = r.get<uint32_t>(), nid = r.get<uint32_t>();
+        if(!r.ok || wid >= n_words || nid >= n_nodes)
+            return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: bad word record");
+        word[nid] = wid;
+    }
+    // children in stream order (m_nodes[parent].children.push_back, :2626)
+    std::vector<uint32_t> coff(n_nodes + 1, 0), fill(n_nodes, 0), child(n_nodes, 0);
+    for(uint32_t i = 0; i < n_nodes; ++i)
+        coff[i + 1] = coff[i] + nchild[i];
+    for(uint32_t i = 1; i < n_nodes; ++i)
+    {
+        const uint32_t nid = order[i], par = parent[nid];
+        child[coff[par] + fill[par]++] = nid;
+    }
+    // slots: BFS so that siblings are contiguous
+    std::vector<uint32_t> slot_node(n_nodes, 0), node_slot(n_nodes, 0);
+    uint32_t next = 1, head = 0;
+    int max_children = 0;
+    if(nchild[0] == 0)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: root has no children");
+    while(head < next)
+    {
+        const uint32_t nid = slot_node[head++];
+        max_children = std::max(max_children, (int)nchild[nid]);
+        for(uint32_t j = 0; j < nchild[nid]; ++j)
+        {
+            const uint32_t ch = child[coff[nid] + j];
+            if(next >= n_nodes)
+                return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: tree is not connected");
+            node_slot[ch] = next;
+            slot_node[next++] = ch;
+        }
+    }
+    if(next != n_nodes)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: unreachable nodes");
+    if(max_children > 65535)
+        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: branching factor too large");
+    std::vector<uint8_t> sdesc((size_t)n_nodes * 32);
+    std::vector<uint32_t> sfirst(n_nodes), snchild(n_nodes), sword(n_nodes);
+    std::vector<double> sweight(n_nodes);
+    for(uint32_t s = 0; s < n_nodes; ++s)
+    {
+        const uint32_t nid = slot_node[s];
+        std::memcpy(&sdesc[(size_t)s * 32], &desc[(size_t)nid * 32], 32);
+        snchild[s] = nchild[nid];
+        sfirst[s] = nchild[nid] ? node_slot[child[coff[nid]]] : 0;
+        sword[s] = word[nid];
+        sweight[s] = weight[nid];
+    }
+
+    if(c->p.max_keypoints > 16384)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_load: max_keypoints > 16384 is not supported by the BoW vector kernel");
+    BowState* b = new BowState();
+    b->k = k, b->L = L, b->scoring = scoring, b->weighting = weighting;
+    b->n_nodes = n_nodes, b->n_words = n_words, b->max_children = max_children;
+    b->cap = c->p.max_keypoints;
+    b->B = c->p.max_batch;
+    b->RP = b->R + b->B;
+    const size_t cap = (size_t)b->cap, B = (size_t)b->B, RP = (size_t)b->RP;
+    auto fail_free = [&](int rc) {
+        bow_destroy(b);
+        return rc;
+    };
+#define BALLOC(ptr, n)                                                                                                 \
+    if(bmalloc(ptr, n) != hipSuccess)                                                                                  \
+    {                                                                                                                  \
+        c->err = "bow_load: device allocation failed";                                                                 \
+        return fail_free(MSLAM_HIP_E_RUNTIME);                                                                         \
+    }
+    BALLOC(b->d_desc, (size_t)n_nodes * 2);
+    BALLOC(b->d_first, n_nodes);
+    BALLOC(b->d_nchild, n_nodes);
+    BALLOC(b->d_word, n_nodes);
+    BALLOC(b->d_weight, n_nodes);
+    BALLOC(b->d_fword, (B + 1) * cap);
+    BALLOC(b->d_fweight, (B + 1) * cap);
+    BALLOC(b->d_bwords, (B + 1) * cap);
+    BALLOC(b->d_bvalues, (B + 1) * cap);
+    BALLOC(b->d_bn, B + 1);
+    BALLOC(b->d_rwords, RP * cap);
+    BALLOC(b->d_rvalues, RP * cap);
+    BALLOC(b->d_rn, RP);
+    BALLOC(b->d_scores, (B + 1) * (size_t)b->R);
+    BALLOC(b->d_best_entry, B + 1);
+    BALLOC(b->d_best_score, B + 1);
+    BALLOC(b->d_hdesc, cap * 32);
+#undef BALLOC
+    bool ok = hipMemcpy(b->d_desc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(b->d_first, sfirst.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(b->d_nchild, snchild.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(b->d_word, sword.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(b->d_weight, sweight.data(), n_nodes * 8, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemset(b->d_rn, 0, RP * 4) == hipSuccess && hipMemset(b->d_bn, 0, (B + 1) * 4) == hipSuccess;
+    if(!ok)
+    {
+        c->err = "bow_load: upload failed";
+        return fail_free(MSLAM_HIP_E_RUNTIME);
+    }
+    if(c->bow)
+        bow_destroy(c->bow);
+    c->bow = b;
+    return MSLAM_HIP_OK;
+}
+
+// transform `n_frames` descriptor sets (device) into BoW vectors at batch slots slot0..; counts from device or fixed
+static int bow_transform_dev(mslam_hip_ctx* c, const uint8_t* d_desc, long long stride, const int32_t* d_counts,
+                             int n_fixed, int n_frames, int slot0)
+{
+    BowState* b = c->bow;
+    hipStream_t s = c->stream;
+    const int cap = b->cap;
+    const int groups_per_block = 256 / kBowGroup;
+    dim3 grid((cap + groups_per_block - 1) / groups_per_block, n_frames);
+    hipLaunchKernelGGL(k_bow_descend, grid, dim3(256), 0, s, d_desc, stride, d_counts, n_fixed, cap, b->d_desc, b->d_first,
+                       b->d_nchild, b->d_word, b->d_weight, b->d_fword + (size_t)slot0 * cap,
+                       b->d_fweight + (size_t)slot0 * cap);
+    const int npow2 = pow2_at_least(cap);
+    if((size_t)npow2 * 8 > 48 * 1024)
+        BHIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_vector),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, npow2 * 8));
+    hipLaunchKernelGGL(k_bow_vector, dim3(n_frames), dim3(VT), (size_t)npow2 * 8, s, b->d_fword + (size_t)slot0 * cap,
+                       b->d_fweight + (size_t)slot0 * cap, d_counts, n_fixed, cap, npow2, b->weighting, b->scoring,
+                       b->d_bwords, b->d_bvalues, b->d_bn, slot0);
+    BHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
+static int bow_score_dev(mslam_hip_ctx* c, int qslot, int n_frames, long long base_id, int per_frame_id)
+{
+    BowState* b = c->bow;
+    int threads = 64;
+    while(threads < b->R)
+        threads <<= 1;
+    hipLaunchKernelGGL(k_bow_score, dim3(1, n_frames), dim3(threads), (size_t)threads * 16, c->stream, b->d_bwords,
+                       b->d_bvalues, b->d_bn, qslot, b->cap, b->d_rwords, b->d_rvalues, b->d_rn, base_id, per_frame_id,
+                       b->R, b->RP, b->d_scores, b->d_best_entry, b->d_best_score);
+    BHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
+int bow_batch(mslam_hip_ctx* c, int add_to_db)
+{
+    BowState* b = c->bow;
+    if(c->n_last < 1)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_batch_dev: no detect batch");
+    const size_t K = (size_t)c->p.max_keypoints;
+    const int n = c->n_last;
+    int rc = bow_transform_dev(c, c->d_desc + K * 32, (long long)K * 32, c->d_count + 1, 0, n, 0);
+    if(rc)
+        return rc;
+    if(add_to_db)
+    {
+        hipLaunchKernelGGL(k_bow_commit, dim3(n), dim3(256), 0, c->stream, b->d_bwords, b->d_bvalues, b->d_bn, b->cap,
+                           b->next_id, b->RP, b->d_rwords, b->d_rvalues, b->d_rn);
+    }
+    rc = bow_score_dev(c, 0, n, b->next_id, add_to_db ? 1 : 0);
+    if(rc)
+        return rc;
+    if(add_to_db)
+        b->next_id += n;
+    return MSLAM_HIP_OK;
+}
+
 } // namespace mslam
 
-static int novoc(mslam_hip_ctx* c)
+using namespace mslam;
+
+static int need_voc(mslam_hip_ctx* c)
 {
     if(!c)
         return MSLAM_HIP_E_INVALID;
-    c->err = "no vocabulary loaded";
-    return MSLAM_HIP_E_NO_VOCABULARY;
+    if(!c->bow)
+    {
+        c->err = "no vocabulary loaded (call mslam_hip_bow_load first)";
+        return MSLAM_HIP_E_NO_VOCABULARY;
+    }
+    return MSLAM_HIP_OK;
+}
+
+// upload n host descriptors and transform them into batch slot B (the host-query slot)
+static int host_transform(mslam_hip_ctx* c, const uint8_t* desc, int n)
+{
+    BowState* b = c->bow;
+    if(n < 0 || n > b->cap || (n > 0 && !desc))
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow: descriptor count outside [0, max_keypoints]");
+    if(n > 0)
+        BHIPCHK(c, hipMemcpyAsync(b->d_hdesc, desc, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    return bow_transform_dev(c, b->d_hdesc, 0, nullptr, n, 1, b->B);
 }
 
 extern "C" {
-int mslam_hip_bow_load(mslam_hip_ctx* c, const void*, size_t) { if(!c) return MSLAM_HIP_E_INVALID; c->err = "bow_load: not built yet"; return MSLAM_HIP_E_FORMAT; }
-int mslam_hip_bow_info(mslam_hip_ctx* c, int*, int*, int*, int*, int*, int*) { return novoc(c); }
-int mslam_hip_bow_words(mslam_hip_ctx* c, const uint8_t*, int, uint32_t*, double*) { return novoc(c); }
-int mslam_hip_bow_transform(mslam_hip_ctx* c, const uint8_t*, int, uint32_t*, double*, int*) { return novoc(c); }
-int mslam_hip_bow_score(mslam_hip_ctx* c, const uint32_t*, const double*, int, const uint32_t*, const double*, int, double*) { return novoc(c); }
-int mslam_hip_bow_db_add(mslam_hip_ctx* c, const uint8_t*, int, int*) { return novoc(c); }
-int mslam_hip_bow_db_query(mslam_hip_ctx* c, const uint8_t*, int, int, int32_t*, double*, int*) { return novoc(c); }
-int mslam_hip_bow_db_clear(mslam_hip_ctx* c) { return novoc(c); }
-int mslam_hip_bow_batch_dev(mslam_hip_ctx* c, int) { return novoc(c); }
-int mslam_hip_get_bow_view(mslam_hip_ctx* c, mslam_hip_bow_view*) { return novoc(c); }
+
+int mslam_hip_bow_load(mslam_hip_ctx* c, const void* blob, size_t size)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(!blob)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_load: null blob");
+    if(hipStreamSynchronize(c->stream) != hipSuccess)
+        return bfail(c, MSLAM_HIP_E_RUNTIME, "bow_load: stream sync failed");
+    return bow_load_impl(c, blob, size);
 }
+
+int mslam_hip_bow_info(mslam_hip_ctx* c, int* k, int* L, int* n_nodes, int* n_words, int* scoring, int* weighting)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    const BowState* b = c->bow;
+    if(k) *k = b->k;
+    if(L) *L = b->L;
+    if(n_nodes) *n_nodes = (int)b->n_nodes;
+    if(n_words) *n_words = (int)b->n_words;
+    if(scoring) *scoring = b->scoring;
+    if(weighting) *weighting = b->weighting;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_words(mslam_hip_ctx* c, const uint8_t* desc, int n, uint32_t* word, double* weight)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    BowState* b = c->bow;
+    if(n == 0)
+        return MSLAM_HIP_OK;
+    if(!word || !weight)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_words: null output");
+    rc = host_transform(c, desc, n);
+    if(rc)
+        return rc;
+    const size_t o = (size_t)b->B * b->cap;
+    BHIPCHK(c, hipMemcpyAsync(word, b->d_fword + o, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    BHIPCHK(c, hipMemcpyAsync(weight, b->d_fweight + o, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    BHIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_transform(mslam_hip_ctx* c, const uint8_t* desc, int n, uint32_t* words, double* values, int* n_words)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    BowState* b = c->bow;
+    if(!n_words)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_transform: null output");
+    *n_words = 0;
+    rc = host_transform(c, desc, n);
+    if(rc)
+        return rc;
+    int32_t m = 0;
+    BHIPCHK(c, hipMemcpyAsync(&m, b->d_bn + b->B, 4, hipMemcpyDeviceToHost, c->stream));
+    BHIPCHK(c, hipStreamSynchronize(c->stream));
+    if(m > 0)
+    {
+        if(!words || !values)
+            return bfail(c, MSLAM_HIP_E_INVALID, "bow_transform: null output");
+        const size_t o = (size_t)b->B * b->cap;
+        BHIPCHK(c, hipMemcpy(words, b->d_bwords + o, (size_t)m * 4, hipMemcpyDeviceToHost));
+        BHIPCHK(c, hipMemcpy(values, b->d_bvalues + o, (size_t)m * 8, hipMemcpyDeviceToHost));
+    }
+    *n_words = m;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_score(mslam_hip_ctx* c, const uint32_t* w1, const double* v1, int n1, const uint32_t* w2,
+                        const double* v2, int n2, double* score)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    BowState* b = c->bow;
+    if(!score || n1 < 0 || n2 < 0 || n1 > b->cap || n2 > b->cap || (n1 > 0 && (!w1 || !v1)) || (n2 > 0 && (!w2 || !v2)))
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_score: bad argument");
+    // vector 1 -> the host-query batch slot, vector 2 -> the per-feature scratch of that slot
+    const size_t o = (size_t)b->B * b->cap;
+    uint32_t* tw = b->d_fword + o;
+    double* tv = b->d_fweight + o;
+    hipStream_t s = c->stream;
+    if(n1 > 0)
+    {
+        BHIPCHK(c, hipMemcpyAsync(b->d_bwords + o, w1, (size_t)n1 * 4, hipMemcpyHostToDevice, s));
+        BHIPCHK(c, hipMemcpyAsync(b->d_bvalues + o, v1, (size_t)n1 * 8, hipMemcpyHostToDevice, s));
+    }
+    if(n2 > 0)
+    {
+        BHIPCHK(c, hipMemcpyAsync(tw, w2, (size_t)n2 * 4, hipMemcpyHostToDevice, s));
+        BHIPCHK(c, hipMemcpyAsync(tv, v2, (size_t)n2 * 8, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_bow_score_pair, dim3(1), dim3(1), 0, s, b->d_bwords + o, b->d_bvalues + o, n1, tw, tv, n2,
+                       b->d_best_score + b->B);
+    BHIPCHK(c, hipGetLastError());
+    BHIPCHK(c, hipMemcpyAsync(score, b->d_best_score + b->B, 8, hipMemcpyDeviceToHost, s));
+    BHIPCHK(c, hipStreamSynchronize(s));
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_db_add(mslam_hip_ctx* c, const uint8_t* desc, int n, int* entry_id)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    BowState* b = c->bow;
+    rc = host_transform(c, desc, n);
+    if(rc)
+        return rc;
+    const size_t o = (size_t)b->B * b->cap;
+    hipLaunchKernelGGL(k_bow_commit, dim3(1), dim3(256), 0, c->stream, b->d_bwords + o, b->d_bvalues + o, b->d_bn + b->B,
+                       b->cap, b->next_id, b->RP, b->d_rwords, b->d_rvalues, b->d_rn);
+    BHIPCHK(c, hipGetLastError());
+    BHIPCHK(c, hipStreamSynchronize(c->stream));
+    if(entry_id)
+        *entry_id = (int)b->next_id;
+    b->next_id += 1;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_db_query(mslam_hip_ctx* c, const uint8_t* desc, int n, int max_results, int32_t* entry_ids,
+                           double* scores, int* n_results)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    BowState* b = c->bow;
+    if(!n_results || max_results < 0 || (max_results > 0 && (!entry_ids || !scores)))
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_db_query: bad argument");
+    *n_results = 0;
+    rc = host_transform(c, desc, n);
+    if(rc)
+        return rc;
+    rc = bow_score_dev(c, b->B, 1, b->next_id, 0);
+    if(rc)
+        return rc;
+    std::vector<double> sc(b->R);
+    BHIPCHK(c, hipMemcpyAsync(sc.data(), b->d_scores + (size_t)b->B * b->R, (size_t)b->R * 8, hipMemcpyDeviceToHost,
+                              c->stream));
+    BHIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<std::pair<double, long long>> res;
+    for(int j = 0; j < b->R; ++j)
+    {
+        const long long id = b->next_id - 1 - j;
+        if(id >= 0 && sc[j] >= 0)
+            res.emplace_back(sc[j], id);
+    }
+    std::sort(res.begin(), res.end(), [](const auto& x, const auto& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+    const int m = std::min<int>(max_results, (int)res.size());
+    for(int i = 0; i < m; ++i)
+    {
+        entry_ids[i] = (int32_t)res[i].second;
+        scores[i] = res[i].first;
+    }
+    *n_results = m;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_db_clear(mslam_hip_ctx* c)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    BHIPCHK(c, hipStreamSynchronize(c->stream));
+    BHIPCHK(c, hipMemset(c->bow->d_rn, 0, (size_t)c->bow->RP * 4));
+    c->bow->next_id = 0;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_batch_dev(mslam_hip_ctx* c, int add_to_db)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    return bow_batch(c, add_to_db);
+}
+
+int mslam_hip_get_bow_view(mslam_hip_ctx* c, mslam_hip_bow_view* v)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    if(!v)
+        return MSLAM_HIP_E_INVALID;
+    const BowState* b = c->bow;
+    v->capacity = b->cap;
+    v->words = b->d_bwords;
+    v->values = b->d_bvalues;
+    v->n_words = b->d_bn;
+    v->best_entry = b->d_best_entry;
+    v->best_score = b->d_best_score;
+    return MSLAM_HIP_OK;
+}
+
+} // extern "C"

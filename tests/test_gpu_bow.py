@@ -1,0 +1,101 @@
+"""GPU parity: DBoW3 word assignment, BoW vectors, L1 scores and the database, against the oracle."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def descs(orc, synth_frames):
+    return [orc.detect(f, orc.params())["desc"] for f in synth_frames[:4]]
+
+
+@pytest.mark.parametrize("k,L,weighting", [(10, 3, 0), (7, 4, 1), (20, 2, 2), (3, 5, 3), (16, 2, 0)])
+def test_words_and_vectors(pkg, orc, descs, k, L, weighting):
+    blob = synth.make_vocabulary(k, L, seed=77 + k, weighting=weighting)
+    V = orc.Vocabulary(blob)
+    c = pkg.Context(width=640, height=480, max_keypoints=4096)
+    c.bow_load(blob)
+    info = c.bow_info()
+    assert (info["k"], info["L"], info["n_nodes"], info["n_words"]) == (V.k, V.L, V.n_nodes, V.n_words)
+    rng = np.random.default_rng(3)
+    for d in (descs[0], rng.integers(0, 256, (1500, 32), dtype=np.uint8), descs[1][:1]):
+        gw, gwt = c.bow_words(d)
+        rw, rwt = V.words(d)
+        assert np.array_equal(gw, rw) and np.array_equal(gwt, rwt)
+        gv = c.bow_transform(d)
+        rv = V.bow_vector(d)
+        assert np.array_equal(gv[0], rv[0])
+        assert np.array_equal(gv[1], rv[1])  # f64, bit-exact: same summation order
+    c.close()
+
+
+def test_scores_and_database(pkg, orc, descs):
+    blob = synth.make_vocabulary(10, 3)
+    V = orc.Vocabulary(blob)
+    c = pkg.Context(width=640, height=480, max_keypoints=4096)
+    c.bow_load(blob)
+    vecs = [V.bow_vector(d) for d in descs]
+    for i in range(4):
+        for j in range(4):
+            assert c.bow_score(*vecs[i], *vecs[j]) == orc.bow_score_l1(*vecs[i], *vecs[j])
+    assert c.bow_score(vecs[0][0][:0], vecs[0][1][:0], *vecs[1]) == 0.0
+    # database: add three frames, query with the fourth and with a copy of the second
+    ids = [c.bow_db_add(d) for d in descs[:3]]
+    assert ids == [0, 1, 2]
+    for q in (descs[3], descs[1]):
+        got_ids, got_sc = c.bow_db_query(q, 3)
+        qv = V.bow_vector(q)
+        exp = sorted(((orc.bow_score_l1(*qv, *vecs[i]), i) for i in range(3)), key=lambda t: (-t[0], t[1]))
+        assert list(got_ids) == [i for _, i in exp]
+        assert list(got_sc) == [s for s, _ in exp]
+    c.bow_db_clear()
+    assert len(c.bow_db_query(descs[0], 3)[0]) == 0
+    c.close()
+
+
+def test_no_vocabulary_is_loud(pkg):
+    c = pkg.Context(width=640, height=480)
+    with pytest.raises(pkg.MslamHipError) as e:
+        c.bow_words(np.zeros((1, 32), np.uint8))
+    assert e.value.code == pkg.E_NO_VOCABULARY
+    with pytest.raises(pkg.MslamHipError) as e:
+        c.bow_load(b"not a vocabulary")
+    assert e.value.code == pkg.E_FORMAT
+    c.close()
+
+
+def test_bow_batch_device(pkg, orc, synth_frames):
+    """detect batch -> BoW vectors -> score against the database (query-then-add per frame)."""
+    import torch
+    blob = synth.make_vocabulary(10, 3)
+    V = orc.Vocabulary(blob)
+    frames = synth_frames[:6]
+    dev = torch.from_numpy(frames).cuda()
+    K = 4096
+    c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=K)
+    c.bow_load(blob)
+    vecs = [V.bow_vector(orc.detect(f, orc.params())["desc"]) for f in frames]
+    for b in range(2):
+        c.detect_batch_dev(dev[3 * b:].data_ptr(), 3)
+        c.bow_batch_dev(True)
+        c.sync()
+        v = c.bow_view()
+        n = pkg.read_device(c, v.n_words, (3,), np.int32)
+        words = pkg.read_device(c, v.words, (3, K), np.uint32)
+        vals = pkg.read_device(c, v.values, (3, K), np.float64)
+        be = pkg.read_device(c, v.best_entry, (3,), np.int32)
+        bs = pkg.read_device(c, v.best_score, (3,), np.float64)
+        for i in range(3):
+            t = 3 * b + i
+            assert n[i] == len(vecs[t][0])
+            assert np.array_equal(words[i, :n[i]], vecs[t][0]) and np.array_equal(vals[i, :n[i]], vecs[t][1])
+            exp = sorted(((orc.bow_score_l1(*vecs[t], *vecs[e]), e) for e in range(t)), key=lambda x: (-x[0], x[1]))
+            exp = [x for x in exp if x[0] > 0]
+            if not exp:
+                assert be[i] == -1
+            else:
+                assert be[i] == exp[0][1] and bs[i] == exp[0][0]
+    c.close()
