@@ -11,7 +11,7 @@
 // Score identity used: for a pixel that passes the 9-contiguous test at threshold t, OpenCV's
 // cornerScore<16>(.., t) equals  S = max(max_arc min(d), max_arc min(-d)) - 1  over the 16 arcs of 9
 // circle pixels (d = v - p), and the pixel passes at threshold t iff S >= t.  So one S map serves both
-// thresholds: map_t = (S >= t ? S : 0).  (Checked against the literal scalar loops in oracle/.)
+// thresholds: map_t = (S >= t ? S : 0).  (The parity tests check this against a literal restatement of the scalar loops.)
 #include "common.hpp"
 
 namespace mslam
