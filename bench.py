@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--unique", type=int, default=200, help="distinct synthetic frames kept in HBM (cycled)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--bow", action="store_true",
+                    help="cfg3/cfg4: also DBoW3 loop scoring every frame (synthetic k=10 vocabulary) and, with "
+                         "N>1, the RCCL all-gather of BoW vectors + cross-stream scoring")
+    ap.add_argument("--voc-levels", type=int, default=6, help="vocabulary depth L (k=10): 6 -> 1e6 words")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames of the stream timed on the CPU oracle")
     return ap.parse_args()
@@ -112,11 +116,20 @@ def main():
     ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, max_keypoints=4096, max_candidates=16384,
                       device=local)
     n_batches = n_unique // B
+    cross = None
+    if a.bow:
+        ctx.bow_load(synth.make_vocabulary(10, a.voc_levels, seed=77))
+        from modular_slam_amd.multi_stream import CrossStreamLoopCandidates
+        cross = CrossStreamLoopCandidates(k_max=2048)
 
     def step(i):
         off = (i % n_batches) * B
         ctx.detect_batch_dev(d_frames.data_ptr() + off * frame_bytes, B)
         ctx.match_batch_dev(0.7, True)
+        if a.bow:
+            ctx.bow_batch_dev(True)
+            if world > 1:
+                cross.step_gpu(ctx)
 
     for i in range(a.warmup):
         step(i)
@@ -182,7 +195,10 @@ def main():
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "cfg2: synthetic %dx%d stream, 8-level ORB (reference defaults 1.2/20/7/min-area 1000), "
-                                   "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame" % (a.width, a.height),
+                                   "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame%s" % (
+                           a.width, a.height, (" + DBoW3 k=10 L=%d loop scoring vs last 64 frames%s" % (
+                               a.voc_levels, " + RCCL all-gather of BoW vectors, cross-stream scores" if world > 1 else ""))
+                           if a.bow else ""),
                        "frames_per_step": B, "frames_per_gpu": a.steps * B, "distinct_frames": n_unique,
                        "keypoints_per_frame": round(kp_b / B, 1), "fast_candidates_per_frame": round(cand_b / B, 1),
                        "frames_per_s": a.steps * B * world / dt_max,

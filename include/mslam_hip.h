@@ -166,6 +166,14 @@ typedef struct
 } mslam_hip_bow_view;
 int mslam_hip_get_bow_view(mslam_hip_ctx* ctx, mslam_hip_bow_view* view);
 
+/* Cross-stream loop candidates (multi-camera / multi-GPU): score the BoW vector of
+ * every frame t of the last mslam_hip_bow_batch_dev against vector [r][t] of n_sets foreign vector
+ * sets (e.g. the all-gathered vectors of the other ranks).  Device arrays: d_words / d_values are
+ * [n_sets][max_batch][capacity], d_n is [n_sets][max_batch], d_scores (out) is [max_batch][n_sets];
+ * a pair without a common word scores exactly 0. */
+int mslam_hip_bow_cross_score_dev(mslam_hip_ctx* ctx, const uint32_t* d_words, const double* d_values,
+                                  const int32_t* d_n, int n_sets, int capacity, double* d_scores);
+
 /* ---- test / debug access to intermediate stages (host copies; synchronises) -----------------------*/
 enum
 {

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "mslam_hip_get_batch_view", "mslam_hip_match", "mslam_hip_match_knn2", "mslam_hip_match_batch_dev",
     "mslam_hip_bow_load", "mslam_hip_bow_info", "mslam_hip_bow_words", "mslam_hip_bow_transform",
     "mslam_hip_bow_score", "mslam_hip_bow_db_add", "mslam_hip_bow_db_query", "mslam_hip_bow_db_clear",
-    "mslam_hip_bow_batch_dev", "mslam_hip_get_bow_view", "mslam_hip_level_geometry", "mslam_hip_debug_read",
+    "mslam_hip_bow_batch_dev", "mslam_hip_get_bow_view", "mslam_hip_bow_cross_score_dev", "mslam_hip_level_geometry", "mslam_hip_debug_read",
     "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host",
 ]
 
@@ -239,6 +239,11 @@ class Context:
 
     def bow_batch_dev(self, add_to_db=True):
         self._chk(self.L.mslam_hip_bow_batch_dev(self._h, int(bool(add_to_db))))
+
+    def bow_cross_score_dev(self, d_words, d_values, d_n, n_sets, capacity, d_scores):
+        self._chk(self.L.mslam_hip_bow_cross_score_dev(self._h, C.c_void_p(d_words), C.c_void_p(d_values),
+                                                       C.c_void_p(d_n), int(n_sets), int(capacity),
+                                                       C.c_void_p(d_scores)))
 
     def bow_view(self):
         v = BowView()

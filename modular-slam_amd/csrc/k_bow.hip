@@ -359,6 +359,44 @@ __global__ void k_bow_score_pair(const uint32_t* __restrict__ w1, const double* 
     *out = -s / 2.0;
 }
 
+// local frame t against foreign vector [r][t]; one thread per (t, r)
+__global__ __launch_bounds__(64) void k_bow_cross_score(const uint32_t* __restrict__ bwords,
+                                                        const double* __restrict__ bvalues,
+                                                        const int32_t* __restrict__ bn, int cap, int n_frames,
+                                                        const uint32_t* __restrict__ fwords,
+                                                        const double* __restrict__ fvalues, const int32_t* __restrict__ fn,
+                                                        int n_sets, int fcap, int max_batch, double* __restrict__ scores)
+{
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if(idx >= n_frames * n_sets)
+        return;
+    const int t = idx / n_sets, r = idx - t * n_sets;
+    const uint32_t* w1 = bwords + (size_t)t * cap;
+    const double* v1 = bvalues + (size_t)t * cap;
+    const int n1 = bn[t];
+    const size_t fo = (size_t)r * max_batch + t;
+    const uint32_t* w2 = fwords + fo * fcap;
+    const double* v2 = fvalues + fo * fcap;
+    const int n2 = min(fn[fo], fcap);
+    int a = 0, b = 0;
+    double s = 0;
+    while(a < n1 && b < n2)
+    {
+        const uint32_t x = w1[a], y = w2[b];
+        if(x == y)
+        {
+            const double vi = v1[a], wi = v2[b];
+            s += fabs(vi - wi) - fabs(vi) - fabs(wi);
+            ++a, ++b;
+        }
+        else if(x < y)
+            ++a;
+        else
+            ++b;
+    }
+    scores[(size_t)t * n_sets + r] = -s / 2.0;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 #define BHIPCHK(c, call)                                                                                               \
     do                                                                                                                 \
@@ -822,6 +860,24 @@ int mslam_hip_bow_batch_dev(mslam_hip_ctx* c, int add_to_db)
     if(rc)
         return rc;
     return bow_batch(c, add_to_db);
+}
+
+int mslam_hip_bow_cross_score_dev(mslam_hip_ctx* c, const uint32_t* d_words, const double* d_values,
+                                  const int32_t* d_n, int n_sets, int capacity, double* d_scores)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    const BowState* b = c->bow;
+    if(!d_words || !d_values || !d_n || !d_scores || n_sets < 1 || capacity < 1)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_cross_score_dev: bad argument");
+    if(c->n_last < 1)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_cross_score_dev: no BoW batch");
+    const int total = c->n_last * n_sets;
+    hipLaunchKernelGGL(k_bow_cross_score, dim3((total + 63) / 64), dim3(64), 0, c->stream, b->d_bwords, b->d_bvalues,
+                       b->d_bn, b->cap, c->n_last, d_words, d_values, d_n, n_sets, capacity, b->B, d_scores);
+    BHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
 }
 
 int mslam_hip_get_bow_view(mslam_hip_ctx* c, mslam_hip_bow_view* v)

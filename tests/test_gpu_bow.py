@@ -99,3 +99,46 @@ def test_bow_batch_device(pkg, orc, synth_frames):
             else:
                 assert be[i] == exp[0][1] and bs[i] == exp[0][0]
     c.close()
+
+
+def test_cross_stream_scores(pkg, orc, synth_frames):
+    """the multi-GPU exchange step on one rank: all-gather (trivial at world 1) + HIP cross scoring"""
+    import torch
+    from modular_slam_amd.multi_stream import CrossStreamLoopCandidates
+    blob = synth.make_vocabulary(10, 3)
+    V = orc.Vocabulary(blob)
+    frames = synth_frames[:6]
+    dev = torch.from_numpy(frames).cuda()
+    B, K, k_max = 3, 4096, 2048
+    c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K)
+    c.bow_load(blob)
+    vecs = [V.bow_vector(orc.detect(f, orc.params())["desc"]) for f in frames]
+    c.detect_batch_dev(dev.data_ptr(), B)
+    c.bow_batch_dev(False)
+    x = CrossStreamLoopCandidates(k_max=k_max)
+    s = x.step_gpu(c).cpu().numpy()
+    assert s.shape == (B, 1)
+    for t in range(B):
+        assert s[t, 0] == orc.bow_score_l1(*vecs[t], *vecs[t])
+    # two foreign streams: frames 3..5 and frames 1,2,0
+    sets = [[3, 4, 5], [1, 2, 0]]
+    W = torch.zeros((2, B, k_max), dtype=torch.int32)
+    Vv = torch.zeros((2, B, k_max), dtype=torch.float64)
+    N = torch.zeros((2, B), dtype=torch.int32)
+    for r, ids in enumerate(sets):
+        for t, i in enumerate(ids):
+            n = len(vecs[i][0])
+            W[r, t, :n] = torch.from_numpy(vecs[i][0].view(np.int32))
+            Vv[r, t, :n] = torch.from_numpy(vecs[i][1])
+            N[r, t] = n
+    W, Vv, N = W.cuda(), Vv.cuda(), N.cuda()
+    out = torch.zeros((B, 2), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    c.bow_cross_score_dev(W.data_ptr(), Vv.data_ptr(), N.data_ptr(), 2, k_max, out.data_ptr())
+    c.sync()
+    out = out.cpu().numpy()
+    for r, ids in enumerate(sets):
+        for t, i in enumerate(ids):
+            assert out[t, r] == orc.bow_score_l1(*vecs[t], *vecs[i])
+    assert CrossStreamLoopCandidates.candidates(out, rank=-1, min_score=0.0)
+    c.close()
