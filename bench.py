@@ -49,7 +49,7 @@ def parse():
     return ap.parse_args()
 
 
-def stage_bytes(ctx, B, n_kp, n_cand):
+def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
     """Algorithmic HBM bytes per LAUNCH for every stage: each input byte read once,
     each output byte written once, for a batch of B frames with n_kp keypoints / n_cand FAST
     candidates in total."""
@@ -65,6 +65,10 @@ def stage_bytes(ctx, B, n_kp, n_cand):
         "describe": B * 2 * P + 48 * n_kp,  # reads both planes around each keypoint, writes desc+xy+angle+octave+resp
         "match_knn2": 2 * 32 * n_kp + 16 * n_kp,
         "ratio_compact": 12 * n_kp + 8 * n_kp,
+        # bow_tree = n*(32 + L*k*32) + n*12 out; vectors are <= n x (u32, f64)
+        "bow_descend": n_kp * (32 + voc_L * voc_k * 32) + 12 * n_kp,
+        "bow_vector": 12 * n_kp + 12 * n_kp,
+        "bow_score": db_entries * 2 * 12 * n_kp,
     }
 
 
@@ -176,7 +180,7 @@ def main():
                 acc[name] = acc.get(name, 0.0) + ms / reps
         ctx.set_profiling(False)
         kp_b, cand_b = counts_per_batch[0], cand_per_batch[0]
-        sb = stage_bytes(ctx, B, kp_b, cand_b)
+        sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)
         dom = max(acc, key=acc.get)
         launches = 7 if dom == "resize" else 1
         achieved = sb[dom] / (acc[dom] * 1e-3) / 1e9

@@ -223,33 +223,6 @@ static hipError_t dmalloc(T*& p, size_t n)
     return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
 }
 
-// ---- stage timing -----------------------------------------------------------------------------------
-struct StageScope
-{
-    mslam_hip_ctx* c;
-    StageTimer* t = nullptr;
-    StageScope(mslam_hip_ctx* ctx, const char* name) : c(ctx)
-    {
-        if(!c->profiling)
-            return;
-        if(c->timers_used == c->timers.size())
-        {
-            StageTimer nt{name, nullptr, nullptr};
-            if(hipEventCreate(&nt.start) != hipSuccess || hipEventCreate(&nt.stop) != hipSuccess)
-                return;
-            c->timers.push_back(nt);
-        }
-        t = &c->timers[c->timers_used++];
-        t->name = name;
-        (void)hipEventRecord(t->start, c->stream);
-    }
-    ~StageScope()
-    {
-        if(t)
-            (void)hipEventRecord(t->stop, c->stream);
-    }
-};
-
 // ---- C ABI ------------------------------------------------------------------------------------------
 extern "C" {
 

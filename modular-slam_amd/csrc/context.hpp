@@ -75,6 +75,34 @@ struct mslam_hip_ctx
 
 namespace mslam
 {
+// records a [start, stop] HIP-event pair on the context's stream around a stage when profiling is on
+struct StageScope
+{
+    mslam_hip_ctx* c;
+    mslam::StageTimer* t = nullptr;
+    StageScope(mslam_hip_ctx* ctx, const char* name) : c(ctx)
+    {
+        if(!c->profiling)
+            return;
+        if(c->timers_used == c->timers.size())
+        {
+            mslam::StageTimer nt{name, nullptr, nullptr};
+            if(hipEventCreate(&nt.start) != hipSuccess || hipEventCreate(&nt.stop) != hipSuccess)
+                return;
+            c->timers.push_back(nt);
+        }
+        t = &c->timers[c->timers_used++];
+        t->name = name;
+        (void)hipEventRecord(t->start, c->stream);
+    }
+    ~StageScope()
+    {
+        if(t)
+            (void)hipEventRecord(t->stop, c->stream);
+    }
+};
+
+
 // bow entry points used by api.hip
 int bow_batch(mslam_hip_ctx* c, int add_to_db);
 } // namespace mslam

@@ -599,18 +599,24 @@ static int bow_transform_dev(mslam_hip_ctx* c, const uint8_t* d_desc, long long 
     BowState* b = c->bow;
     hipStream_t s = c->stream;
     const int cap = b->cap;
-    const int groups_per_block = 256 / kBowGroup;
-    dim3 grid((cap + groups_per_block - 1) / groups_per_block, n_frames);
-    hipLaunchKernelGGL(k_bow_descend, grid, dim3(256), 0, s, d_desc, stride, d_counts, n_fixed, cap, b->d_desc, b->d_first,
-                       b->d_nchild, b->d_word, b->d_weight, b->d_fword + (size_t)slot0 * cap,
-                       b->d_fweight + (size_t)slot0 * cap);
-    const int npow2 = pow2_at_least(cap);
-    if((size_t)npow2 * 8 > 48 * 1024)
-        BHIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_vector),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, npow2 * 8));
-    hipLaunchKernelGGL(k_bow_vector, dim3(n_frames), dim3(VT), (size_t)npow2 * 8, s, b->d_fword + (size_t)slot0 * cap,
-                       b->d_fweight + (size_t)slot0 * cap, d_counts, n_fixed, cap, npow2, b->weighting, b->scoring,
-                       b->d_bwords, b->d_bvalues, b->d_bn, slot0);
+    {
+        StageScope t(c, "bow_descend");
+        const int groups_per_block = 256 / kBowGroup;
+        dim3 grid((cap + groups_per_block - 1) / groups_per_block, n_frames);
+        hipLaunchKernelGGL(k_bow_descend, grid, dim3(256), 0, s, d_desc, stride, d_counts, n_fixed, cap, b->d_desc,
+                           b->d_first, b->d_nchild, b->d_word, b->d_weight, b->d_fword + (size_t)slot0 * cap,
+                           b->d_fweight + (size_t)slot0 * cap);
+    }
+    {
+        StageScope t(c, "bow_vector");
+        const int npow2 = pow2_at_least(cap);
+        if((size_t)npow2 * 8 > 48 * 1024)
+            BHIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_vector),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, npow2 * 8));
+        hipLaunchKernelGGL(k_bow_vector, dim3(n_frames), dim3(VT), (size_t)npow2 * 8, s, b->d_fword + (size_t)slot0 * cap,
+                           b->d_fweight + (size_t)slot0 * cap, d_counts, n_fixed, cap, npow2, b->weighting, b->scoring,
+                           b->d_bwords, b->d_bvalues, b->d_bn, slot0);
+    }
     BHIPCHK(c, hipGetLastError());
     return MSLAM_HIP_OK;
 }
@@ -618,6 +624,7 @@ static int bow_transform_dev(mslam_hip_ctx* c, const uint8_t* d_desc, long long 
 static int bow_score_dev(mslam_hip_ctx* c, int qslot, int n_frames, long long base_id, int per_frame_id)
 {
     BowState* b = c->bow;
+    StageScope t3(c, "bow_score");
     int threads = 64;
     while(threads < b->R)
         threads <<= 1;

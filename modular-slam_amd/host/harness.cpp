@@ -1,0 +1,84 @@
+// harness.cpp — a minimal C++ host that uses the plugin exactly as the reference would:
+// loadFactoryMethod<T>(library, alias) (plugin_loader.hpp:20-24, as in test/plugin_loader_test.cpp:17-21),
+// then the call order of RgbdFeatureFrontend::processSensorData: detect(frame_t) ->
+// match(from = keypoints_t, to = keypoints_{t-1}) (rgbd_feature_frontend.cpp:187,237).
+//
+// usage: mslam_harness <plugin.so> <width> <height> <frame0.bgr> <frame1.bgr> [--load-only]
+// prints one line per frame/match with an FNV-1a checksum the parity test compares with the oracle's.
+#include "mslam_interfaces.hpp"
+#include "plugin_loader.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+static std::uint32_t fnv(const void* p, std::size_t n, std::uint32_t h = 0x811C9DC5u)
+{
+    const auto* b = static_cast<const unsigned char*>(p);
+    for(std::size_t i = 0; i < n; ++i)
+        h = (h ^ b[i]) * 0x01000193u;
+    return h;
+}
+
+int main(int argc, char** argv)
+{
+    if(argc < 2)
+    {
+        std::fprintf(stderr, "usage: %s <plugin> [<width> <height> <frame0.bgr> <frame1.bgr>]\n", argv[0]);
+        return 2;
+    }
+    try
+    {
+        auto makeDetector = mslam::loadFactoryMethod<mslam::IOrbFeatureDetector>(argv[1], "hipOrbDetectorFactory");
+        auto makeMatcher = mslam::loadFactoryMethod<mslam::IOrbMatcher>(argv[1], "hipOrbMatcherFactory");
+        if(!makeDetector || !makeMatcher)
+            return 3;
+        std::unique_ptr<mslam::IOrbFeatureDetector> detector = makeDetector();
+        std::unique_ptr<mslam::IOrbMatcher> matcher = makeMatcher();
+        std::printf("loaded %s\n", detector && matcher ? "ok" : "null");
+        if(argc < 6)
+            return detector && matcher ? 0 : 4;
+        const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+        std::vector<mslam::OrbKeypoint> prev;
+        for(int f = 0; f < 2; ++f)
+        {
+            mslam::RgbFrame frame;
+            frame.size = {w, h};
+            frame.data.resize(static_cast<std::size_t>(w) * h * 3);
+            std::ifstream in(argv[4 + f], std::ios::binary);
+            if(!in.read(reinterpret_cast<char*>(frame.data.data()), static_cast<std::streamsize>(frame.data.size())))
+            {
+                std::fprintf(stderr, "cannot read %s\n", argv[4 + f]);
+                return 5;
+            }
+            auto kps = detector->detect(frame);
+            std::uint32_t hc = 0x811C9DC5u;
+            for(const auto& k : kps)
+            {
+                const double xy[2] = {k.keypoint.coordinates.x(), k.keypoint.coordinates.y()};
+                hc = fnv(&k.keypoint.id, 8, hc);
+                hc = fnv(xy, 16, hc);
+                hc = fnv(k.descriptor.data(), 32, hc);
+            }
+            std::printf("frame %d keypoints %zu fnv %08x\n", f, kps.size(), hc);
+            if(f > 0)
+            {
+                auto m = matcher->match(kps, prev);
+                std::uint32_t hm = 0x811C9DC5u;
+                for(const auto& d : m)
+                {
+                    const std::uint64_t ft[2] = {d.fromIndex, d.toIndex};
+                    hm = fnv(ft, 16, hm);
+                }
+                std::printf("match %d pairs %zu fnv %08x\n", f, m.size(), hm);
+            }
+            prev = std::move(kps);
+        }
+    }
+    catch(const std::exception& e)
+    {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,215 @@
+// mslam_hip_plugin.cpp — adapters from the reference's plugin interfaces to the C ABI (mslam_hip.h),
+// and the factory aliases the reference's loader imports.
+//
+//   HipOrbDetector    : IFeatureDetector<RgbFrame,u8,32>   drop-in for DistributedOrbOpenCvDetector
+//                                                           (distributed_cv_feature.cpp:1181-1222)
+//   HipOrbMatcher     : IFeatureMatcher<u8,32>             drop-in for OrbOpenCvMatcher (orb_feature.cpp:84-130)
+//   HipOrbRelocalizer : IRelocalizer + ILoopDetector       what OrbRelocalizer is wired for
+//                                                           (orb_relocalizer.cpp:26-50, rgbd_feature_frontend.cpp:153,176)
+//
+// Errors: the reference interfaces have no status channel, so a non-zero C-ABI status becomes a
+// std::runtime_error carrying mslam_hip_last_error() (the reference itself lets OpenCV/DBoW3 throw,
+// orb_relocalizer.cpp:28).  No CPU fallback exists.
+#include "mslam_interfaces.hpp"
+#include "plugin_loader.hpp"
+
+#include "../../include/mslam_hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+namespace mslam
+{
+namespace
+{
+[[noreturn]] void raise(mslam_hip_ctx* ctx, const char* what, int rc)
+{
+    std::string msg = std::string("mslam_hip: ") + what + " failed (" + std::to_string(rc) + "): " + mslam_hip_last_error(ctx);
+    std::fprintf(stderr, "[error] %s\n", msg.c_str());
+    throw std::runtime_error(msg);
+}
+
+struct Ctx
+{
+    mslam_hip_ctx* h = nullptr;
+    int width = 0, height = 0;
+    void ensure(int w, int h_)
+    {
+        if(h && w == width && h_ == height)
+            return;
+        if(h)
+            mslam_hip_destroy(h);
+        h = nullptr;
+        mslam_hip_params p;
+        mslam_hip_default_params(&p); // the reference's hard-coded operating point
+        p.width = w;
+        p.height = h_;
+        const int rc = mslam_hip_create(&p, &h);
+        if(rc != MSLAM_HIP_OK)
+            raise(nullptr, "mslam_hip_create", rc);
+        width = w;
+        height = h_;
+    }
+    ~Ctx()
+    {
+        if(h)
+            mslam_hip_destroy(h);
+    }
+};
+
+void gather_descriptors(const std::vector<OrbKeypoint>& kps, std::vector<std::uint8_t>& out)
+{
+    out.resize(kps.size() * 32);
+    for(std::size_t i = 0; i < kps.size(); ++i)
+        std::memcpy(&out[i * 32], kps[i].descriptor.data(), 32);
+}
+} // namespace
+
+class HipOrbDetector : public IOrbFeatureDetector
+{
+  public:
+    std::vector<OrbKeypoint> detect(const RgbFrame& sensorData) override
+    {
+        std::vector<OrbKeypoint> result;
+        if(sensorData.data.empty()) // distributed_cv_feature.cpp:724-727: empty image => empty result
+            return result;
+        ctx.ensure(sensorData.size.width, sensorData.size.height);
+        const int cap = 8192;
+        xy.resize(2 * cap);
+        desc.resize(32 * cap);
+        int n = 0;
+        const int rc = mslam_hip_detect(ctx.h, sensorData.data.data(), sensorData.size.width, sensorData.size.height, cap,
+                                        xy.data(), desc.data(), nullptr, nullptr, nullptr, &n);
+        if(rc != MSLAM_HIP_OK)
+            raise(ctx.h, "mslam_hip_detect", rc);
+        result.resize(static_cast<std::size_t>(n));
+        for(int i = 0; i < n; ++i)
+        {
+            // distributed_cv_feature.cpp:1203-1213: id = running index, float coordinates widened to double
+            result[i].keypoint.id = static_cast<Id>(i);
+            result[i].keypoint.coordinates.x() = xy[2 * i];
+            result[i].keypoint.coordinates.y() = xy[2 * i + 1];
+            std::memcpy(result[i].descriptor.data(), &desc[32 * i], 32);
+        }
+        return result;
+    }
+
+  private:
+    Ctx ctx;
+    std::vector<float> xy;
+    std::vector<std::uint8_t> desc;
+};
+
+class HipOrbMatcher : public IOrbMatcher
+{
+  public:
+    std::vector<DescriptorMatch> match(const std::vector<OrbKeypoint>& fromDescriptors,
+                                       const std::vector<OrbKeypoint>& toDescriptors) override
+    {
+        ctx.ensure(640, 480); // the matcher does not depend on the frame size
+        gather_descriptors(fromDescriptors, from);
+        gather_descriptors(toDescriptors, to);
+        fi.resize(toDescriptors.size() + 1);
+        ti.resize(toDescriptors.size() + 1);
+        int n = 0;
+        const int rc = mslam_hip_match(ctx.h, from.data(), static_cast<int>(fromDescriptors.size()), to.data(),
+                                       static_cast<int>(toDescriptors.size()), 0.7 /* orb_feature.cpp:101 */, fi.data(),
+                                       ti.data(), &n);
+        if(rc != MSLAM_HIP_OK)
+            raise(ctx.h, "mslam_hip_match", rc);
+        std::vector<DescriptorMatch> matches(static_cast<std::size_t>(n));
+        for(int i = 0; i < n; ++i)
+            matches[i] = DescriptorMatch{static_cast<std::size_t>(fi[i]), static_cast<std::size_t>(ti[i])};
+        return matches;
+    }
+
+  private:
+    Ctx ctx;
+    std::vector<std::uint8_t> from, to;
+    std::vector<std::int32_t> fi, ti;
+};
+
+class HipOrbRelocalizer : public IOrbRelocalizer, public IOrbLoopDetector
+{
+  public:
+    using KeyframePtr = std::shared_ptr<Keyframe<slam3d::SensorState>>;
+
+    // like OrbRelocalizer (orb_relocalizer.cpp:26-30): loads "orbvoc.dbow3" from the working directory and
+    // throws when it is missing.  The file must be an uncompressed DBoW3 binary vocabulary.
+    explicit HipOrbRelocalizer(const std::string& vocabularyPath = "orbvoc.dbow3")
+    {
+        std::ifstream f(vocabularyPath, std::ios::binary);
+        if(!f)
+            throw std::runtime_error("HipOrbRelocalizer: could not open vocabulary " + vocabularyPath);
+        std::vector<char> blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        ctx.ensure(640, 480);
+        const int rc = mslam_hip_bow_load(ctx.h, blob.data(), blob.size());
+        if(rc != MSLAM_HIP_OK)
+            raise(ctx.h, "mslam_hip_bow_load", rc);
+    }
+
+    std::vector<KeyframePtr> relocalize(const std::vector<OrbKeypoint>& keypoints) override
+    {
+        gather_descriptors(keypoints, desc);
+        std::int32_t ids[64];
+        double scores[64];
+        int n = 0;
+        const int rc = mslam_hip_bow_db_query(ctx.h, desc.data(), static_cast<int>(keypoints.size()), 64, ids, scores, &n);
+        if(rc != MSLAM_HIP_OK)
+            raise(ctx.h, "mslam_hip_bow_db_query", rc);
+        std::vector<KeyframePtr> out;
+        for(int i = 0; i < n && out.size() < 4; ++i)
+        {
+            auto it = entryToKeyframe.find(ids[i]);
+            if(it != entryToKeyframe.end())
+                out.push_back(it->second);
+        }
+        return out;
+    }
+
+    void addKeyframe(KeyframePtr keyframe, const std::vector<OrbKeypoint>& keypoints) override
+    {
+        if(keypoints.empty()) // the reference asserts non-empty (orb_relocalizer.cpp:42)
+            return;
+        // loop candidate = best earlier keyframe for the one being added (ILoopDetector has no arguments,
+        // loop_detection.hpp:13, so it is fed here — rgbd_feature_frontend.cpp:176 is the only feed point)
+        const auto candidates = relocalize(keypoints);
+        lastLoop = candidates.empty() ? nullptr : candidates.front();
+        int entry = -1;
+        const int rc = mslam_hip_bow_db_add(ctx.h, desc.data(), static_cast<int>(keypoints.size()), &entry);
+        if(rc != MSLAM_HIP_OK)
+            raise(ctx.h, "mslam_hip_bow_db_add", rc);
+        entryToKeyframe[entry] = std::move(keyframe);
+    }
+
+    void removeKeyframe(KeyframePtr keyframe) override
+    {
+        for(auto it = entryToKeyframe.begin(); it != entryToKeyframe.end();)
+            it = it->second == keyframe ? entryToKeyframe.erase(it) : std::next(it);
+    }
+
+    KeyframePtr detectLoop() override { return lastLoop; }
+
+  private:
+    Ctx ctx;
+    std::vector<std::uint8_t> desc;
+    std::map<int, KeyframePtr> entryToKeyframe;
+    KeyframePtr lastLoop;
+};
+
+// ---- factories + aliases (what loadFactoryMethod<T>(lib, name) imports) -------------------------------
+std::unique_ptr<IOrbFeatureDetector> createHipOrbDetector() { return std::make_unique<HipOrbDetector>(); }
+std::unique_ptr<IOrbMatcher> createHipOrbMatcher() { return std::make_unique<HipOrbMatcher>(); }
+std::unique_ptr<IOrbRelocalizer> createHipOrbRelocalizer() { return std::make_unique<HipOrbRelocalizer>(); }
+std::unique_ptr<IOrbLoopDetector> createHipLoopDetector() { return std::make_unique<HipOrbRelocalizer>(); }
+
+} // namespace mslam
+
+MSLAM_DLL_ALIAS(mslam::createHipOrbDetector, hipOrbDetectorFactory)
+MSLAM_DLL_ALIAS(mslam::createHipOrbMatcher, hipOrbMatcherFactory)
+MSLAM_DLL_ALIAS(mslam::createHipOrbRelocalizer, hipOrbRelocalizerFactory)
+MSLAM_DLL_ALIAS(mslam::createHipLoopDetector, loopDetection) // key used by test/plugin_config.json
