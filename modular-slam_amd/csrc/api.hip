@@ -279,7 +279,7 @@ static int create_impl(mslam_hip_ctx* c)
     const mslam_hip_params& p = c->p;
     if(p.width <= 0 || p.height <= 0 || p.max_batch < 1 || p.n_levels < 1 || p.n_levels > kMaxLevels ||
        !(p.scale_factor > 1.0f) || p.ini_fast_thr < 0 || p.ini_fast_thr > 255 || p.min_fast_thr < 0 ||
-       p.min_fast_thr > p.ini_fast_thr || p.max_keypoints < 1 || p.max_candidates < 1 ||
+       p.min_fast_thr > p.ini_fast_thr || p.max_keypoints < 1 || p.max_keypoints > 65535 || p.max_candidates < 1 ||
        p.max_candidates > (1 << 22))
         return fail(c, MSLAM_HIP_E_INVALID, "invalid parameters");
     if(!umax_table_ok())
@@ -677,6 +677,8 @@ int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from,
         return MSLAM_HIP_E_INVALID;
     if(n_from < 0 || n_to < 0 || (n_from > 0 && !from_desc) || (n_to > 0 && (!to_desc || !idx0 || !idx1 || !dist0 || !dist1)))
         return fail(c, MSLAM_HIP_E_INVALID, "match_knn2: bad argument");
+    if(n_from > 65535)
+        return fail(c, MSLAM_HIP_E_INVALID, "match_knn2: more than 65535 train descriptors are not supported");
     if(n_to == 0)
         return MSLAM_HIP_OK;
     int rc = host_match_prepare(c, from_desc, n_from, to_desc, n_to);
@@ -703,6 +705,8 @@ int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, cons
         *n_out = 0;
     if(!n_out || n_from < 0 || n_to < 0 || (n_from > 0 && !from_desc) || (n_to > 0 && (!to_desc || !from_idx || !to_idx)))
         return fail(c, MSLAM_HIP_E_INVALID, "match: bad argument");
+    if(n_from > 65535)
+        return fail(c, MSLAM_HIP_E_INVALID, "match: more than 65535 train descriptors are not supported");
     if(n_to == 0 || n_from < 2)
         return MSLAM_HIP_OK; // reference: UB for n_from < 2 (orb_feature.cpp:101); defined here as no matches
     int rc = upload_ratio_table(c, ratio);

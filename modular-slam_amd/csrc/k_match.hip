@@ -4,11 +4,9 @@
 // BFMatcher(NORM_HAMMING).knnMatch(query = to, train = from, k = 2) then the ratio test and the
 // (fromIndex = trainIdx, toIndex = queryIdx) output in query order.
 //
-// k_match_knn2: one lane owns one query descriptor (4 x u64 in registers).  Train descriptors are
-// staged through LDS in 256-row tiles; every lane of a wave reads the SAME train row, which the LDS
-// serves as a broadcast (no bank conflicts), so the inner loop is 4 xor + 4 popcount + the top-2
-// update.  Scan order is ascending train index and both comparisons are strict, so on equal
-// distances the lower train index ranks first — exactly batchDistance's insertion rule.
+// k_match_knn2: one lane owns one query descriptor (8 dwords in registers); train rows arrive through
+// the scalar unit (see the kernel).  On equal distances the lower train index ranks first — exactly
+// batchDistance's insertion rule (strict `<` on insertion while scanning train rows in ascending order).
 // Not HBM-bound: inputs are 2*K*32 bytes against K^2 popcount-compares.
 #include "common.hpp"
 #include <climits>
@@ -16,80 +14,129 @@
 namespace mslam
 {
 
-constexpr int kMT = 256; // queries per workgroup == train rows per LDS tile
-
-__global__ __launch_bounds__(kMT) void k_match_knn2(MatchArgs a)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
 {
-    __shared__ uint4 tile[kMT * 2]; // 256 descriptors x 32 B
+    // v_bcnt_u32_b32 d, x, acc = popcount(x) + acc in ONE instruction; written as asm because the
+    // compiler otherwise re-associates the eight partial sums into popcounts + separate adds
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+
+// A train row is the same for every lane of a wave, so it is fetched with SCALAR loads (s_load_dwordx8
+// through the scalar cache) and used as an SGPR operand of the per-lane xor: no LDS staging, no vector
+// memory traffic in the loop.  Each lane owns QL queries; MW waves of a workgroup scan disjoint slices
+// of the train rows for the same queries.  The top-2 of a query is kept as two packed keys
+// (distance << 16 | train index): keys are unique and ordered by (distance, index), so
+// best0' = min(best0, key), best1' = med3(best0, best1, key) is exactly batchDistance's insertion
+// rule, and the partial results of the waves merge exactly.
+template <int MW, int QL, int UNR>
+__global__ __launch_bounds__(64 * MW) void k_match_knn2(MatchArgs a)
+{
+    __shared__ uint32_t part[MW][QL][2][64];
 
     const int pair = blockIdx.y;
-    const int n_from = a.from_cnt ? a.from_cnt[pair] : a.n_from_fixed;
+    const int n_from = min(a.from_cnt ? a.from_cnt[pair] : a.n_from_fixed, 65535);
     const int n_to = min(a.to_cnt ? a.to_cnt[pair] : a.n_to_fixed, a.cap);
-    const int q0 = blockIdx.x * kMT;
+    const int q0 = blockIdx.x * (64 * QL);
     if(q0 >= n_to)
         return;
-    const int tid = threadIdx.x;
-    const int q = q0 + tid;
-    const uint8_t* from = a.from_desc + (long long)pair * a.from_stride;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t* __restrict__ from =
+        reinterpret_cast<const uint32_t*>(a.from_desc + (long long)pair * a.from_stride);
     const uint8_t* to = a.to_desc + (long long)pair * a.to_stride;
 
-    unsigned long long qd0 = 0, qd1 = 0, qd2 = 0, qd3 = 0;
-    if(q < n_to)
+    uint4 qa[QL], qb[QL];
+    uint32_t best0[QL], best1[QL];
+#pragma unroll
+    for(int u = 0; u < QL; ++u)
     {
-        const uint4* qp = reinterpret_cast<const uint4*>(to + (size_t)q * 32);
-        const uint4 lo = qp[0], hi = qp[1];
-        qd0 = lo.x | ((unsigned long long)lo.y << 32);
-        qd1 = lo.z | ((unsigned long long)lo.w << 32);
-        qd2 = hi.x | ((unsigned long long)hi.y << 32);
-        qd3 = hi.z | ((unsigned long long)hi.w << 32);
-    }
-    int best0 = INT_MAX, best1 = INT_MAX, i0 = -1, i1 = -1;
-
-    for(int base = 0; base < n_from; base += kMT)
-    {
-        const int rows = min(kMT, n_from - base);
-        __syncthreads();
-        // 512 uint4 per tile, 2 per thread, coalesced
-        for(int k = tid; k < rows * 2; k += kMT)
-            tile[k] = reinterpret_cast<const uint4*>(from + (size_t)base * 32)[k];
-        __syncthreads();
-        const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(tile);
-#pragma unroll 4
-        for(int j = 0; j < rows; ++j)
+        const int q = q0 + u * 64 + lane;
+        qa[u] = make_uint4(0, 0, 0, 0);
+        qb[u] = qa[u];
+        if(q < n_to)
         {
-            const int d = __popcll(qd0 ^ t64[4 * j]) + __popcll(qd1 ^ t64[4 * j + 1]) + __popcll(qd2 ^ t64[4 * j + 2]) +
-                          __popcll(qd3 ^ t64[4 * j + 3]);
-            if(d < best1)
-            {
-                if(d < best0)
+            const uint4* qp = reinterpret_cast<const uint4*>(to + (size_t)q * 32);
+            qa[u] = qp[0];
+            qb[u] = qp[1];
+        }
+        best0[u] = best1[u] = 0xFFFFFFFFu;
+    }
+    const int chunk = (n_from + MW - 1) / MW;
+    const int j0 = wave * chunk, j1 = min(n_from, j0 + chunk);
+    auto row = [&](int j) {
+        const uint32_t* __restrict__ t = from + (size_t)j * 8; // wave-uniform address -> s_load_dwordx8
+        const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6], t7 = t[7];
+#pragma unroll
+        for(int u = 0; u < QL; ++u)
+        {
+            uint32_t d = __popc(qa[u].x ^ t0);
+            d = bcnt_acc(qa[u].y ^ t1, d);
+            d = bcnt_acc(qa[u].z ^ t2, d);
+            d = bcnt_acc(qa[u].w ^ t3, d);
+            d = bcnt_acc(qb[u].x ^ t4, d);
+            d = bcnt_acc(qb[u].y ^ t5, d);
+            d = bcnt_acc(qb[u].z ^ t6, d);
+            d = bcnt_acc(qb[u].w ^ t7, d);
+            const uint32_t key = (d << 16) | (uint32_t)j;
+            best1[u] = min(max(best0[u], key), best1[u]);
+            best0[u] = min(best0[u], key);
+        }
+    };
+    int j = j0;
+    for(; j + UNR <= j1; j += UNR)
+    {
+#pragma unroll
+        for(int k = 0; k < UNR; ++k)
+            row(j + k);
+    }
+    for(; j < j1; ++j)
+        row(j);
+#pragma unroll
+    for(int u = 0; u < QL; ++u)
+    {
+        part[wave][u][0][lane] = best0[u];
+        part[wave][u][1][lane] = best1[u];
+    }
+    __syncthreads();
+    // wave u merges the partial top-2 of query slice u
+    for(int u = wave; u < QL; u += MW)
+    {
+        const int q = q0 + u * 64 + lane;
+        if(q < n_to)
+        {
+            uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
+#pragma unroll
+            for(int w = 0; w < MW; ++w)
+#pragma unroll
+                for(int k = 0; k < 2; ++k)
                 {
-                    best1 = best0;
-                    i1 = i0;
-                    best0 = d;
-                    i0 = base + j;
+                    const uint32_t key = part[w][u][k][lane];
+                    b1 = min(max(b0, key), b1);
+                    b0 = min(b0, key);
                 }
-                else
-                {
-                    best1 = d;
-                    i1 = base + j;
-                }
-            }
+            const size_t o = (size_t)pair * a.cap + q;
+            a.idx0[o] = b0 == 0xFFFFFFFFu ? -1 : (int32_t)(b0 & 0xFFFFu);
+            a.idx1[o] = b1 == 0xFFFFFFFFu ? -1 : (int32_t)(b1 & 0xFFFFu);
+            a.dist0[o] = b0 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b0 >> 16);
+            a.dist1[o] = b1 == 0xFFFFFFFFu ? INT_MAX : (int32_t)(b1 >> 16);
         }
     }
-    if(q < n_to)
-    {
-        const size_t o = (size_t)pair * a.cap + q;
-        a.idx0[o] = i0;
-        a.idx1[o] = i1;
-        a.dist0[o] = best0;
-        a.dist1[o] = best1;
-    }
+}
+
+template <int MW, int QL, int UNR>
+static void launch_variant(const MatchArgs& a, int n_pairs, hipStream_t s)
+{
+    dim3 grid((a.cap + 64 * QL - 1) / (64 * QL), n_pairs);
+    hipLaunchKernelGGL((k_match_knn2<MW, QL, UNR>), grid, dim3(64 * MW), 0, s, a);
 }
 
 void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
 {
-    dim3 grid((a.cap + kMT - 1) / kMT, n_pairs);
-    hipLaunchKernelGGL(k_match_knn2, grid, dim3(kMT), 0, s, a);
+    // 8 waves x 1 query per lane, 8 rows per scalar-load batch: measured fastest of the variants tried
+    // (the loop is bound by integer VALU issue: 8 xor + 8 bcnt + 4 top-2 ops per pair).
+    launch_variant<8, 1, 8>(a, n_pairs, s);
 }
 
 // ratio test (orb_feature.cpp:99-105) + ordered compaction (:110-114); one workgroup per pair
