@@ -4,58 +4,57 @@
 // for every 64-px cell (70x70 sub-image with the 6-px overlap) cv::FAST(sub, thr=ini, nms=true) and,
 // only if that cell yields nothing, cv::FAST(sub, thr=min, nms=true) (:918-926).
 //
-// One 256-thread workgroup per (cell, frame).  The 70x70 tile is staged in LDS once; a wave owns 16
-// rows and its 64 lanes own the 64 tested columns, so a row's keypoints are one __ballot and the
-// reference's row-major output order falls out of popcounts (no atomics-order dependence).
-//
-// Score identity used: for a pixel that passes the 9-contiguous test at threshold t, OpenCV's
-// cornerScore<16>(.., t) equals  S = max(max_arc min(d), max_arc min(-d)) - 1  over the 16 arcs of 9
-// circle pixels (d = v - p), and the pixel passes at threshold t iff S >= t.  So one S map serves both
-// thresholds: map_t = (S >= t ? S : 0).  (The parity tests check this against a literal restatement of the scalar loops.)
+// One 256-thread workgroup per (cell, frame).  The kernel is integer-VALU bound, so it is organised
+// to spend instructions only where corners can be:
+//   A. every tested pixel takes the 4-point compass test (a 9-arc always contains two adjacent
+//      compass points of one polarity); survivors are compacted into an LDS list with one ballot per row;
+//   B. the list is processed densely (all 64 lanes busy): 16 circle reads and the arc score
+//        S = max(max_arc min(d), max_arc min(-d)) - 1,   d = centre - circle pixel,
+//      over the 16 arcs of 9 pixels, with 3-input min/max.  For a pixel that passes the 9-contiguous
+//      test at threshold t this is OpenCV's cornerScore<16>(.., t), and it passes iff S >= t, so the
+//      test itself never has to be evaluated separately;
+//   C. listed pixels with S >= t are checked against their 8 neighbours in the LDS score map (strict >)
+//      and set one bit in a 64x64 bitmap; row popcounts of the bitmap give the reference's row-major
+//      output order with no dependence on atomic ordering.
+// If the cell is empty at the first threshold the same three steps run again with the fallback one.
 #include "common.hpp"
 
 namespace mslam
 {
 
-constexpr int kTileP = 72; // tile row pitch (bytes)
-constexpr int kScP = 68;   // score row pitch
+constexpr int kTileP = 76; // tile row pitch in bytes: 19 dwords, column 0 = sub-image column -3 (dword aligned)
+constexpr int kTileX = 3;  // tile column of sub-image column 0
+constexpr int kScP = 68;   // score-map row pitch
 
-__device__ __forceinline__ bool has_arc9(uint32_t m16)
-{
-    const uint32_t m = m16 | (m16 << 16);
-    uint32_t x = m & (m >> 1);
-    x &= x >> 2;
-    x &= x >> 4;
-    x &= m >> 8;
-    return (x & 0xFFFFu) != 0;
-}
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
 __device__ __forceinline__ int arc_score(const int (&d)[16])
 {
-    // sliding min / max of width 9 over the circular sequence d[0..15], by doubling
-    int mn2[16], mx2[16];
+    // window-9 min and max over the circular sequence: two levels of 3-input ops
+    int mn3[16], mx3[16];
 #pragma unroll
     for(int i = 0; i < 16; ++i)
     {
-        mn2[i] = min(d[i], d[(i + 1) & 15]);
-        mx2[i] = max(d[i], d[(i + 1) & 15]);
+        mn3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
+        mx3[i] = max3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
     }
-    int mn4[16], mx4[16];
+    int mn9[16], mx9[16];
 #pragma unroll
     for(int i = 0; i < 16; ++i)
     {
-        mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
-        mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
+        mn9[i] = min3i(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
+        mx9[i] = max3i(mx3[i], mx3[(i + 3) & 15], mx3[(i + 6) & 15]);
     }
-    int q0 = -1000, q1 = 1000;
+    int q0 = max3i(mn9[0], mn9[1], mn9[2]), q1 = min3i(mx9[0], mx9[1], mx9[2]);
 #pragma unroll
-    for(int i = 0; i < 16; ++i)
+    for(int i = 3; i < 15; i += 2)
     {
-        const int mn9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
-        const int mx9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
-        q0 = max(q0, mn9);
-        q1 = min(q1, mx9);
+        q0 = max3i(q0, mn9[i], mn9[i + 1]);
+        q1 = min3i(q1, mx9[i], mx9[i + 1]);
     }
+    q0 = max(q0, mn9[15]);
+    q1 = min(q1, mx9[15]);
     return max(q0, -q1) - 1;
 }
 
@@ -63,10 +62,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                                                     const CellDesc* __restrict__ cells, uint32_t* __restrict__ cell_cnt,
                                                     uint32_t* __restrict__ cell_kp, int ini_thr, int min_thr)
 {
-    __shared__ uint8_t tile[70 * kTileP];
-    __shared__ uint8_t sc[66 * kScP];
-    __shared__ uint32_t row_cnt[64];
-    __shared__ uint32_t total;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileP];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kScP];
+    __shared__ uint16_t cand[64 * 64];
+    __shared__ uint32_t bitmap[64 * 2];
+    __shared__ uint32_t n_cand;
 
     const int cell_id = blockIdx.x;
     const size_t frame = blockIdx.y;
@@ -75,141 +75,149 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const int cw = c.cw, ch = c.ch;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // zero the score map (untested pixels must read 0, like FAST_t's zeroed row buffers)
+    // zero the score map (untested pixels must read 0, like FAST_t's zeroed row buffers) and the bitmap
     for(int i = tid; i < 66 * kScP / 4; i += 256)
         reinterpret_cast<uint32_t*>(sc)[i] = 0;
-    if(tid < 64)
-        row_cnt[tid] = 0;
+    if(tid < 128)
+        bitmap[tid] = 0;
     if(tid == 0)
-        total = 0;
+        n_cand = 0;
 
-    // stage the sub-image
-    const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + c.x0;
-    for(int r = wave; r < ch; r += 4)
+    // stage the sub-image with aligned dword loads: x0 - 3 is a multiple of 4 (x0 = 19 + 64 j)
     {
-        const uint8_t* s = src + (size_t)r * lv.pitch;
-        if(lane < cw)
-            tile[r * kTileP + lane] = s[lane];
-        if(lane + 64 < cw)
-            tile[r * kTileP + lane + 64] = s[lane + 64];
-    }
-    __syncthreads();
-
-    // score map: S for pixels that are corners at min_thr (superset of the corners at ini_thr)
-    const int x = lane + 3;
-    const bool col_ok = x < cw - 3;
-#pragma unroll 1
-    for(int r = 0; r < 16; ++r)
-    {
-        const int y = 3 + wave * 16 + r;
-        if(!(col_ok && y < ch - 3))
-            continue;
-        const uint8_t* p = &tile[y * kTileP + x];
-        const int v = p[0];
-        int d[16];
-        d[0] = v - p[3 * kTileP];
-        d[1] = v - p[3 * kTileP + 1];
-        d[2] = v - p[2 * kTileP + 2];
-        d[3] = v - p[kTileP + 3];
-        d[4] = v - p[3];
-        d[5] = v - p[-kTileP + 3];
-        d[6] = v - p[-2 * kTileP + 2];
-        d[7] = v - p[-3 * kTileP + 1];
-        d[8] = v - p[-3 * kTileP];
-        d[9] = v - p[-3 * kTileP - 1];
-        d[10] = v - p[-2 * kTileP - 2];
-        d[11] = v - p[-kTileP - 3];
-        d[12] = v - p[-3];
-        d[13] = v - p[kTileP - 3];
-        d[14] = v - p[2 * kTileP - 2];
-        d[15] = v - p[3 * kTileP - 1];
-        uint32_t dark = 0, bright = 0; // circle pixel darker / brighter than the centre by more than min_thr
-#pragma unroll
-        for(int k = 0; k < 16; ++k)
+        const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - kTileX);
+        const int n_dw = ch * 19;
+        for(int i = tid; i < n_dw; i += 256)
         {
-            dark |= (uint32_t)(d[k] > min_thr) << k;
-            bright |= (uint32_t)(d[k] < -min_thr) << k;
+            const int r = i / 19, q = i - r * 19;
+            reinterpret_cast<uint32_t*>(tile)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 4 * q);
         }
-        if(has_arc9(dark) || has_arc9(bright))
-            sc[(y - 2) * kScP + (x - 2)] = (uint8_t)arc_score(d);
     }
     __syncthreads();
 
-    // NMS at ini_thr; fall back to min_thr only when the whole cell is empty (:922-926)
-    uint32_t flags = 0; // bit r: (row 16*wave+r, this column) is a keypoint
+    const int x = lane + 3; // tested columns: 3 <= x < cw - 3
+    const bool col_ok = x < cw - 3;
+    uint32_t total = 0;
     for(int pass = 0; pass < 2; ++pass)
     {
         const int thr = pass == 0 ? ini_thr : min_thr;
-        flags = 0;
+
+        // ---- A. compass test + compaction
 #pragma unroll 1
         for(int r = 0; r < 16; ++r)
         {
             const int y = 3 + wave * 16 + r;
-            bool kp = false;
+            bool keep = false;
             if(col_ok && y < ch - 3)
             {
-                const uint8_t* q = &sc[(y - 2) * kScP + (x - 2)];
-                const int s = q[0];
-                if(s >= thr && s > 0)
+                const uint8_t* p = &tile[y * kTileP + x + kTileX];
+                const int v = p[0];
+                const int hi = v + thr, lo = v - thr;
+                const int p0 = p[3 * kTileP], p4 = p[3], p8 = p[-3 * kTileP], p12 = p[-3];
+                const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+                const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
+                keep = ((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12));
+            }
+            const unsigned long long b = __ballot(keep);
+            if(b != 0)
+            {
+                uint32_t base = 0;
+                if(lane == 0)
+                    base = atomicAdd(&n_cand, (uint32_t)__popcll(b));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if(keep)
+                    cand[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((y << 8) | x);
+            }
+        }
+        __syncthreads();
+        const uint32_t n = n_cand;
+
+        // ---- B. arc score of the survivors
+        for(uint32_t i = tid; i < n; i += 256)
+        {
+            const uint32_t cxy = cand[i];
+            const int cy = (int)(cxy >> 8), cx = (int)(cxy & 0xFF);
+            const uint8_t* p = &tile[cy * kTileP + cx + kTileX];
+            const int v = p[0];
+            int d[16];
+            d[0] = v - p[3 * kTileP];
+            d[1] = v - p[3 * kTileP + 1];
+            d[2] = v - p[2 * kTileP + 2];
+            d[3] = v - p[kTileP + 3];
+            d[4] = v - p[3];
+            d[5] = v - p[-kTileP + 3];
+            d[6] = v - p[-2 * kTileP + 2];
+            d[7] = v - p[-3 * kTileP + 1];
+            d[8] = v - p[-3 * kTileP];
+            d[9] = v - p[-3 * kTileP - 1];
+            d[10] = v - p[-2 * kTileP - 2];
+            d[11] = v - p[-kTileP - 3];
+            d[12] = v - p[-3];
+            d[13] = v - p[kTileP - 3];
+            d[14] = v - p[2 * kTileP - 2];
+            d[15] = v - p[3 * kTileP - 1];
+            const int s = arc_score(d);
+            if(s >= thr && s > 0)
+                sc[(cy - 2) * kScP + (cx - 2)] = (uint8_t)s;
+        }
+        __syncthreads();
+
+        // ---- C. 3x3 strict non-max suppression over the listed pixels -> bitmap
+        for(uint32_t i = tid; i < n; i += 256)
+        {
+            const uint32_t cxy = cand[i];
+            const int cy = (int)(cxy >> 8), cx = (int)(cxy & 0xFF);
+            const uint8_t* q = &sc[(cy - 2) * kScP + (cx - 2)];
+            const int s = q[0];
+            if(s >= thr && s > 0)
+            {
+                const int m = max(max3i(q[-kScP - 1], q[-kScP], q[-kScP + 1]),
+                                  max(max3i(q[-1], q[1], q[kScP - 1]), max(q[kScP], q[kScP + 1])));
+                if(s > m)
+                    atomicOr(&bitmap[(cy - 3) * 2 + ((cx - 3) >> 5)], 1u << ((cx - 3) & 31));
+            }
+        }
+        __syncthreads();
+
+        // ---- ordered emission: row r of the bitmap = tested row r + 3, bit = tested column - 3
+        if(wave == 0)
+        {
+            const unsigned long long m = bitmap[lane * 2] | ((unsigned long long)bitmap[lane * 2 + 1] << 32);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            uint32_t inc = cnt;
+#pragma unroll
+            for(int o = 1; o < 64; o <<= 1)
+            {
+                const uint32_t t = __shfl_up(inc, o);
+                if(lane >= o)
+                    inc += t;
+            }
+            total = __shfl(inc, 63);
+            if(total != 0)
+            {
+                uint32_t* out = cell_kp + (frame * g.n_cells + cell_id) * (size_t)kCellCap;
+                uint32_t pos = inc - cnt;
+                unsigned long long rest = m;
+                const int y = lane + 3;
+                while(rest)
                 {
-                    // neighbours below thr are non-corners at this threshold: their map value is 0
-                    int m = 0;
-                    int n;
-                    n = q[-kScP - 1]; m = max(m, n >= thr ? n : 0);
-                    n = q[-kScP];     m = max(m, n >= thr ? n : 0);
-                    n = q[-kScP + 1]; m = max(m, n >= thr ? n : 0);
-                    n = q[-1];        m = max(m, n >= thr ? n : 0);
-                    n = q[1];         m = max(m, n >= thr ? n : 0);
-                    n = q[kScP - 1];  m = max(m, n >= thr ? n : 0);
-                    n = q[kScP];      m = max(m, n >= thr ? n : 0);
-                    n = q[kScP + 1];  m = max(m, n >= thr ? n : 0);
-                    kp = s > m;
+                    const int bx = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    out[pos++] = pack_kp(bx + 3 + c.ox, y + c.oy, sc[(y - 2) * kScP + (bx + 3 - 2)]);
                 }
             }
-            const unsigned long long b = __ballot(kp);
-            if(kp)
-                flags |= 1u << r;
             if(lane == 0)
-                row_cnt[wave * 16 + r] = (uint32_t)__popcll(b);
+                n_cand = total != 0 ? 0xFFFFFFFFu : 0u; // tells the other waves whether to run the fallback pass
         }
         __syncthreads();
-        if(tid < 64)
-        {
-            uint32_t v = row_cnt[tid];
-            for(int o = 32; o > 0; o >>= 1)
-                v += __shfl_xor(v, o);
-            if(tid == 0)
-                total = v;
-        }
+        const bool done = n_cand != 0;
         __syncthreads();
-        if(total != 0 || pass == 1)
+        if(done || pass == 1)
             break;
-        __syncthreads(); // everyone has read `total` before row_cnt/total are rewritten
+        // fallback pass: the map written so far (S >= ini_thr) is a subset of the fallback map; n_cand is 0 again
     }
-
-    const uint32_t n_total = total;
-    uint32_t* out = cell_kp + (frame * g.n_cells + cell_id) * (size_t)kCellCap;
     if(tid == 0)
-        cell_cnt[frame * g.n_cells + cell_id] = n_total;
-    if(n_total == 0)
-        return;
-    // ordered emission: rows ascending, columns ascending inside a row
-    uint32_t base = 0;
-    for(int rr = 0; rr < wave * 16; ++rr)
-        base += row_cnt[rr];
-#pragma unroll 1
-    for(int r = 0; r < 16; ++r)
-    {
-        const bool kp = (flags >> r) & 1u;
-        const unsigned long long b = __ballot(kp);
-        if(kp)
-        {
-            const int y = 3 + wave * 16 + r;
-            const uint32_t pos = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-            out[pos] = pack_kp(x + c.ox, y + c.oy, sc[(y - 2) * kScP + (x - 2)]);
-        }
-        base += (uint32_t)__popcll(b);
-    }
+        cell_cnt[frame * g.n_cells + cell_id] = total;
 }
 
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
