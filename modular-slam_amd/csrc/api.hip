@@ -129,8 +129,8 @@ static int build_geometry(mslam_hip_ctx* c)
     for(int l = 1; l < p.n_levels; ++l)
         scale[l] = p.scale_factor * scale[l - 1];
     unsigned offset = 0;
+    int n_strips = 0;
     c->cells.clear();
-    c->tiles.clear();
     for(int l = 0; l < p.n_levels; ++l)
     {
         LevelGeom& lv = g.lv[l];
@@ -184,12 +184,11 @@ static int build_geometry(mslam_hip_ctx* c)
         if(lv.n_cells > 2048)
             return fail(c, MSLAM_HIP_E_INVALID, "more than 2048 FAST cells on one level");
 
-        // blur tiles 64x32
-        lv.tile_base = (int)c->tiles.size();
-        for(int y = 0; y < lv.h; y += 32)
-            for(int x = 0; x < lv.w; x += 64)
-                c->tiles.push_back(BlurTile{(int16_t)l, (int16_t)x, (int16_t)y, 0});
-        lv.n_tiles = (int)c->tiles.size() - lv.tile_base;
+        // blur strips: one thread per 4 columns x kBlurRows rows
+        lv.bsx = (lv.w + 3) / 4;
+        lv.tile_base = n_strips;
+        lv.n_tiles = lv.bsx * ((lv.h + kBlurRows - 1) / kBlurRows);
+        n_strips += lv.n_tiles;
 
         // quadtree initial grid (:1031-1052) on the bordered rectangle [19, w-19) x [19, h-19)
         const int min_x = kBorder, max_x = lv.w - kBorder, min_y = kBorder, max_y = lv.h - kBorder;
@@ -213,7 +212,7 @@ static int build_geometry(mslam_hip_ctx* c)
     }
     g.slab = offset + 256;
     g.n_cells = (int)c->cells.size();
-    g.n_tiles = (int)c->tiles.size();
+    g.n_tiles = n_strips;
     return MSLAM_HIP_OK;
 }
 
@@ -253,7 +252,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
         return;
     if(c->stream)
         (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_cells,   c->d_tiles,  c->d_rs_ofs, c->d_rs_coef, c->d_ratio_thr, c->d_stage,  c->d_pyr,
+    void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_ratio_thr, c->d_stage,  c->d_pyr,
                     c->d_blur,    c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_xy, c->d_desc, c->d_octave,
@@ -311,8 +310,6 @@ static int create_impl(mslam_hip_ctx* c)
     // tables
     HIPCHK(c, dmalloc(c->d_cells, c->cells.size()));
     HIPCHK(c, hipMemcpy(c->d_cells, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
-    HIPCHK(c, dmalloc(c->d_tiles, c->tiles.size()));
-    HIPCHK(c, hipMemcpy(c->d_tiles, c->tiles.data(), c->tiles.size() * sizeof(BlurTile), hipMemcpyHostToDevice));
     {
         std::vector<int32_t> ofs;
         std::vector<uint32_t> coef;
@@ -467,7 +464,7 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
     }
     {
         StageScope t(c, "blur");
-        launch_blur(c->d_pyr, c->d_blur, g, c->d_tiles, n_frames, s);
+        launch_blur(c->d_pyr, c->d_blur, g, n_frames, s);
     }
     {
         StageScope t(c, "describe");

@@ -23,8 +23,9 @@ struct LevelGeom
     int bw, bh;     // bordered width/height = w-38, h-38
     int cell_base;  // index of this level's first cell in the cell table
     int n_cells;    // cells kept after the skip rule (:881-905)
-    int tile_base;  // first blur tile of this level
-    int n_tiles;
+    int tile_base;  // blur: index of this level's first strip thread
+    int n_tiles;    // blur: strip threads of this level = bsx * ceil(h / kBlurRows)
+    int bsx;        // blur: 4-px strips per row = ceil(w / 4)
     // quadtree initial grid (:1031-1052)
     int nxg, nyg;
     double delta_x, delta_y;
@@ -47,10 +48,7 @@ struct CellDesc
     int16_t ox, oy; // j*64, i*64: added to cell-relative coordinates (:940-941)
 };
 
-struct BlurTile
-{
-    int16_t level, x0, y0, pad;
-};
+constexpr int kBlurRows = 32; // output rows per blur strip thread
 
 // candidate / selected keypoint: (Y << 20) | (X << 8) | score, X/Y relative to the (19,19) border origin
 __host__ __device__ inline uint32_t pack_kp(int x, int y, int score) { return ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)score; }
@@ -94,8 +92,7 @@ struct QuadArgs
     unsigned min_size;
 };
 void launch_quadtree(const Geometry& g, const QuadArgs& a, int n_frames, hipStream_t s);
-void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, const BlurTile* d_tiles, int n_frames,
-                 hipStream_t s);
+void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int n_frames, hipStream_t s);
 struct DescArgs
 {
     const uint8_t* pyr;

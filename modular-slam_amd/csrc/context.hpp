@@ -28,11 +28,9 @@ struct mslam_hip_ctx
 
     // host copies of the tables
     std::vector<mslam::CellDesc> cells;
-    std::vector<mslam::BlurTile> tiles;
 
     // device tables
     mslam::CellDesc* d_cells = nullptr;
-    mslam::BlurTile* d_tiles = nullptr;
     int32_t* d_rs_ofs = nullptr;   // resize offsets, all levels
     uint32_t* d_rs_coef = nullptr; // resize coefficients, all levels
     std::vector<size_t> rs_x, rs_y; // per-level start index into d_rs_*

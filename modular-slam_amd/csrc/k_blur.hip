@@ -2,84 +2,153 @@
 //
 // Replaces the per-level clone + cv::GaussianBlur(7x7, 2, 2, BORDER_REFLECT_101) of the reference
 // (distributed_cv_feature.cpp:797-798).  OpenCV's CV_8U path is integer-only: taps in unsigned 8.8
-// fixed point {18,34,48,56,48,34,18} (sum 256), horizontal pass u8*8.8 -> 8.8, vertical pass
-// 8.8*8.8 -> 16.16 rounded by (v + 2^15) >> 16.  The taps are passed in by the host, which derives
-// them with OpenCV's error-diffusion rule (api.hip: gaussian_taps_fixed).
+// fixed point {18,34,48,56,48,34,18} (sum 256), horizontal pass u8*8.8 -> 8.8 (exact, <= 65280),
+// vertical pass 8.8*8.8 -> 16.16 rounded by (v + 2^15) >> 16.  The taps come from the host, which
+// derives them with OpenCV's error-diffusion rule (api.hip: gaussian_taps_fixed).
 //
-// One 256-thread workgroup per 64x32 output tile: the 70x38 source window (REFLECT_101 at the image
-// edges) is staged in LDS, the horizontal pass writes a 16-bit LDS plane, the vertical pass streams
-// out one coalesced 64-byte row segment per wave.
+// The kernel is VALU-bound, so it is built on the packed dot-product instructions:
+//   * one lane owns a strip of 4 columns x 32 rows and walks down it; per source row it loads three
+//     aligned dwords (12 bytes around its 4 columns) straight from global memory (rows are read by
+//     neighbouring lanes too, so L1 serves the overlap) — no LDS, no barriers;
+//   * horizontal 7-tap = two v_dot4_u32_u8 per pixel on byte windows cut with v_alignbyte_b32;
+//   * vertical 7-tap   = three v_dot2_u32_u16 on packed (row, row+1) pairs + one mad per pixel, with
+//     the rounding constant folded into the first accumulate;
+//   * REFLECT_101 at the left/right image edges is applied to the three dwords with four v_perm_b32
+//     whose selectors are computed once per lane (identity for interior lanes), so there is no
+//     divergent edge path; top/bottom reflection is an index computation per row.
+// The row loop is fully unrolled so the sliding window lives in registers without moves.
 #include "common.hpp"
 
 namespace mslam
 {
-
-constexpr int kBW = 64, kBH = 32;
-constexpr int kRawP = 72;
-
-__device__ __forceinline__ int reflect101(int p, int len)
-{
-    if(len == 1)
-        return 0;
-    while(p < 0 || p >= len)
-        p = p < 0 ? -p : 2 * (len - 1) - p;
-    return p;
-}
 
 struct Taps
 {
     int t[7];
 };
 
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, Geometry g,
-                                              const BlurTile* __restrict__ tiles, Taps taps)
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t dot2u(uint32_t pair, uint32_t taps, uint32_t acc)
 {
-    __shared__ uint8_t raw[(kBH + 6) * kRawP];
-    __shared__ uint16_t hb[(kBH + 6) * kBW];
-
-    const BlurTile t = tiles[blockIdx.x];
-    const size_t frame = blockIdx.y;
-    const LevelGeom& lv = g.lv[t.level];
-    const uint8_t* src = pyr + frame * g.slab + lv.offset;
-    uint8_t* dst = blur + frame * g.slab + lv.offset;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    for(int r = wave; r < kBH + 6; r += 4)
-    {
-        const int sy = reflect101(t.y0 - 3 + r, lv.h);
-        const uint8_t* s = src + (size_t)sy * lv.pitch;
-        raw[r * kRawP + lane] = s[reflect101(t.x0 - 3 + lane, lv.w)];
-        if(lane < 6)
-            raw[r * kRawP + 64 + lane] = s[reflect101(t.x0 - 3 + 64 + lane, lv.w)];
-    }
-    __syncthreads();
-    for(int idx = tid; idx < (kBH + 6) * kBW; idx += 256)
-    {
-        const int r = idx >> 6, c = idx & 63;
-        const uint8_t* p = &raw[r * kRawP + c];
-        uint32_t acc = 0;
-#pragma unroll
-        for(int k = 0; k < 7; ++k)
-            acc += (uint32_t)taps.t[k] * p[k];
-        hb[idx] = (uint16_t)acc; // <= 255*256, exact
-    }
-    __syncthreads();
-    for(int idx = tid; idx < kBH * kBW; idx += 256)
-    {
-        const int r = idx >> 6, c = idx & 63;
-        const int x = t.x0 + c, y = t.y0 + r;
-        if(x >= lv.w || y >= lv.h)
-            continue;
-        uint32_t acc = 0;
-#pragma unroll
-        for(int k = 0; k < 7; ++k)
-            acc += (uint32_t)taps.t[k] * hb[(r + k) * kBW + c];
-        dst[(size_t)y * lv.pitch + x] = (uint8_t)min(255u, (acc + 32768u) >> 16);
-    }
+    ushort2v a, b;
+    a.x = (unsigned short)(pair & 0xFFFF);
+    a.y = (unsigned short)(pair >> 16);
+    b.x = (unsigned short)(taps & 0xFFFF);
+    b.y = (unsigned short)(taps >> 16);
+    return __builtin_amdgcn_udot2(a, b, acc, false);
 }
 
-void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, const BlurTile* d_tiles, int n_frames,
-                 hipStream_t s);
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, Geometry g,
+                                              Taps taps)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if(idx >= g.n_tiles)
+        return;
+    int level = 0;
+#pragma unroll 1
+    for(int l = 1; l < g.n_levels; ++l)
+        if(idx >= g.lv[l].tile_base)
+            level = l;
+    const LevelGeom& lv = g.lv[level];
+    const int sidx = idx - lv.tile_base;
+    const int band = sidx / lv.bsx;
+    const int x0 = (sidx - band * lv.bsx) * 4;
+    const int y0 = band * kBlurRows;
+    const int w = lv.w, h = lv.h, pitch = lv.pitch;
+    const size_t frame = blockIdx.y;
+    const uint8_t* src = pyr + frame * g.slab + lv.offset;
+    uint8_t* dst = blur + frame * g.slab + lv.offset;
+
+    // ---- per-lane REFLECT_101 selectors for the 12-byte window [x0-4, x0+8)
+    uint32_t selA = 0, selB = 0, selT = 0, selU = 0, maskT = 0;
+#pragma unroll
+    for(int i = 0; i < 12; ++i)
+    {
+        int col = x0 - 4 + i;
+        if(col < 0)
+            col = -col;
+        else if(col >= w)
+            col = 2 * (w - 1) - col;
+        int s = col - (x0 - 4); // source byte index inside the unreflected window
+        if(s < 0 || s > 11)
+            s = i; // only feeds outputs that are discarded
+        const int b = i & 3;
+        if(i < 4)
+            selA |= (uint32_t)(s <= 7 ? s : i) << (8 * b);
+        else if(i < 8)
+            selB |= (uint32_t)(s <= 7 ? s : i) << (8 * b);
+        else if(s < 4)
+        {
+            selT |= (uint32_t)s << (8 * b);
+            maskT |= 0xFFu << (8 * b);
+        }
+        else
+            selU |= (uint32_t)(s - 4) << (8 * b);
+    }
+    const int offA = max(x0 - 4, 0), offC = min(x0 + 4, pitch - 4);
+
+    const uint32_t t0123 = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 8) | ((uint32_t)taps.t[2] << 16) | ((uint32_t)taps.t[3] << 24);
+    const uint32_t t456 = (uint32_t)taps.t[4] | ((uint32_t)taps.t[5] << 8) | ((uint32_t)taps.t[6] << 16);
+    const uint32_t t01 = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 16);
+    const uint32_t t23 = (uint32_t)taps.t[2] | ((uint32_t)taps.t[3] << 16);
+    const uint32_t t45 = (uint32_t)taps.t[4] | ((uint32_t)taps.t[5] << 16);
+    const uint32_t t6 = (uint32_t)taps.t[6];
+
+    uint32_t pr[6][4]; // pr[m % 6][j] = (h[m][j], h[m+1][j]) packed, for the last six row pairs
+    uint32_t hprev[4] = {0, 0, 0, 0};
+#pragma unroll
+    for(int i = 0; i < kBlurRows + 6; ++i)
+    {
+        int yy = y0 - 3 + i;
+        yy = yy < 0 ? -yy : yy;
+        yy = yy >= h ? 2 * (h - 1) - yy : yy;
+        const uint8_t* row = src + (size_t)yy * pitch;
+        const uint32_t A = *reinterpret_cast<const uint32_t*>(row + offA);
+        const uint32_t B = *reinterpret_cast<const uint32_t*>(row + x0);
+        const uint32_t C = *reinterpret_cast<const uint32_t*>(row + offC);
+        const uint32_t A2 = __builtin_amdgcn_perm(B, A, selA);
+        const uint32_t B2 = __builtin_amdgcn_perm(B, A, selB);
+        const uint32_t T = __builtin_amdgcn_perm(B, A, selT);
+        const uint32_t U = __builtin_amdgcn_perm(C, B, selU);
+        const uint32_t C2 = (T & maskT) | (U & ~maskT);
+        // horizontal pass: output column j uses window bytes j+1 .. j+7
+        uint32_t hv[4];
+        hv[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B2, A2, 1), t0123,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C2, B2, 1), t456, 0u, false), false);
+        hv[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B2, A2, 2), t0123,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C2, B2, 2), t456, 0u, false), false);
+        hv[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B2, A2, 3), t0123,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C2, B2, 3), t456, 0u, false), false);
+        hv[3] = __builtin_amdgcn_udot4(B2, t0123, __builtin_amdgcn_udot4(C2, t456, 0u, false), false);
+        if(i >= 1)
+        {
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+                pr[(i - 1) % 6][j] = hprev[j] | (hv[j] << 16); // pair (row i-1, row i)
+        }
+        if(i >= 6)
+        {
+            // vertical pass for output row o = y0 + i - 6: source rows i-6 .. i
+            uint32_t out = 0;
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+            {
+                uint32_t acc = dot2u(pr[(i - 6) % 6][j], t01, 32768u);
+                acc = dot2u(pr[(i - 4) % 6][j], t23, acc);
+                acc = dot2u(pr[(i - 2) % 6][j], t45, acc);
+                acc += hv[j] * t6;
+                out |= (acc >> 16) << (8 * j);
+            }
+            const int o = y0 + i - 6;
+            if(o < h)
+                *reinterpret_cast<uint32_t*>(dst + (size_t)o * pitch + x0) = out;
+        }
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+            hprev[j] = hv[j];
+    }
+}
 
 static Taps g_taps = {{18, 34, 48, 56, 48, 34, 18}};
 void set_blur_taps(const int* t)
@@ -88,11 +157,10 @@ void set_blur_taps(const int* t)
         g_taps.t[i] = t[i];
 }
 
-void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, const BlurTile* d_tiles, int n_frames,
-                 hipStream_t s)
+void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int n_frames, hipStream_t s)
 {
-    dim3 grid(g.n_tiles, n_frames);
-    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, d_pyr, d_blur, g, d_tiles, g_taps);
+    dim3 grid((g.n_tiles + 255) / 256, n_frames);
+    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, d_pyr, d_blur, g, g_taps);
 }
 
 } // namespace mslam
