@@ -97,9 +97,9 @@ static void gaussian_taps_fixed(int taps[7])
     taps[n2] = (int)(256 - total);
 }
 
-static bool umax_table_ok()
+static bool umax_table(int* out16)
 {
-    // orb_impl ctor, distributed_cv_feature.cpp:522-541; the kernel hard-codes the result
+    // orb_impl ctor, distributed_cv_feature.cpp:522-541
     static const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     int u[17] = {0};
     const int hp = 15;
@@ -114,7 +114,30 @@ static bool umax_table_ok()
         u[v] = (int)v0;
         ++v0;
     }
+    std::memcpy(out16, u, sizeof(expect));
     return std::memcmp(u, expect, sizeof(expect)) == 0;
+}
+
+// Disc weights for the intensity centroid (ic_angle, :543-570): entry t = 8*row + column group covers
+// the 4 pixels u = -15+4c .. -12+4c of row v = t/8 - 15; byte = u (first table) / v (second table) when
+// the pixel lies in the radius-15 disc (|u| <= u_max[|v|]), else 0.
+static void build_orient_weights(const int* umax, uint32_t* w /* [2][256] */)
+{
+    std::memset(w, 0, 2 * 256 * sizeof(uint32_t));
+    for(int t = 0; t < 31 * 8; ++t)
+    {
+        const int v = t / 8 - 15, c = t % 8;
+        for(int j = 0; j < 4; ++j)
+        {
+            const int u = -15 + 4 * c + j;
+            const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+            if(au <= 15 && au <= umax[av])
+            {
+                w[t] |= (uint32_t)(uint8_t)(int8_t)u << (8 * j);
+                w[256 + t] |= (uint32_t)(uint8_t)(int8_t)v << (8 * j);
+            }
+        }
+    }
 }
 
 static int build_geometry(mslam_hip_ctx* c)
@@ -252,7 +275,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
         return;
     if(c->stream)
         (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_ratio_thr, c->d_stage,  c->d_pyr,
+    void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_ratio_thr, c->d_orient_w, c->d_stage,  c->d_pyr,
                     c->d_blur,    c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_xy, c->d_desc, c->d_octave,
@@ -281,7 +304,8 @@ static int create_impl(mslam_hip_ctx* c)
        p.min_fast_thr > p.ini_fast_thr || p.max_keypoints < 1 || p.max_keypoints > 65535 || p.max_candidates < 1 ||
        p.max_candidates > (1 << 22))
         return fail(c, MSLAM_HIP_E_INVALID, "invalid parameters");
-    if(!umax_table_ok())
+    int umax[16];
+    if(!umax_table(umax))
         return fail(c, MSLAM_HIP_E_INVALID, "u_max table self-check failed");
     int taps[7];
     gaussian_taps_fixed(taps);
@@ -330,6 +354,12 @@ static int create_impl(mslam_hip_ctx* c)
         HIPCHK(c, hipMemcpy(c->d_rs_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
     }
     HIPCHK(c, dmalloc(c->d_ratio_thr, 257));
+    {
+        uint32_t w[2 * 256];
+        build_orient_weights(umax, w);
+        HIPCHK(c, dmalloc(c->d_orient_w, 2 * 256));
+        HIPCHK(c, hipMemcpy(c->d_orient_w, w, sizeof(w), hipMemcpyHostToDevice));
+    }
 
     const size_t B = (size_t)p.max_batch, L = (size_t)p.n_levels, cap = (size_t)p.max_candidates;
     const size_t K = (size_t)p.max_keypoints;
@@ -473,6 +503,7 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
         a.blur = c->d_blur;
         a.sel = c->quad.sel;
         a.sel_cnt = c->quad.sel_cnt;
+        a.orient_w = c->d_orient_w;
         a.cand_cap = c->p.max_candidates;
         a.max_kp = c->p.max_keypoints;
         a.xy = c->d_xy + K * 2;

@@ -99,6 +99,7 @@ struct DescArgs
     const uint8_t* blur;
     const uint32_t* sel;
     const uint32_t* sel_cnt;
+    const uint32_t* orient_w; // [2][256] disc weights: u bytes, then v bytes (api.hip: build_orient_weights)
     int cand_cap;
     int max_kp;
     float* xy;

@@ -35,6 +35,7 @@ struct mslam_hip_ctx
     uint32_t* d_rs_coef = nullptr; // resize coefficients, all levels
     std::vector<size_t> rs_x, rs_y; // per-level start index into d_rs_*
     int32_t* d_ratio_thr = nullptr; // [257]
+    uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
     double ratio_cached = -1.0;
 
     // device working set (sized for max_batch frames)

@@ -4,11 +4,9 @@
 // level, :977), compute_orb_descriptor scalar branch (:572-629, on the blurred level, :797-801),
 // correct_keypoint_scale (:1166-1179) and the output packing of detect() (:1200-1214).
 //
-// One wave per keypoint.  Orientation: lanes 0..30 each own one column u of the radius-15 disc and
-// walk its rows, so every step of the walk reads 31 consecutive bytes; the integer moments are
-// reduced across the wave (exact, order-free).  Descriptor: lane i evaluates pairs i, i+64, i+128,
-// i+192, so the four __ballot masks ARE descriptor bytes 0-7, 8-15, 16-23, 24-31 (bit i of byte j =
-// pair 8j+i, LSB first, :614-625).  All float arithmetic is individually rounded (no FMA) and follows
+// One wave per keypoint (see k_describe).  Descriptor: lane i evaluates pairs i, i+64, i+128, i+192, so
+// the four __ballot masks ARE descriptor bytes 0-7, 8-15, 16-23, 24-31 (bit i of byte j = pair 8j+i,
+// LSB first, :614-625).  All float arithmetic is individually rounded (no FMA) and follows
 // the reference expression order; cvRound = round-half-even, cvFloor = floor.
 #include "common.hpp"
 #include "../../include/mslam_orb_pattern.h"
@@ -16,9 +14,8 @@
 namespace mslam
 {
 
-__constant__ int8_t c_pattern[1024] = MSLAM_ORB_PATTERN_INIT;
-// u_max_ of orb_impl's constructor (:522-541) for half patch 15; api.hip recomputes and checks it.
-__constant__ int8_t c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// the sampling pattern as floats (x0, y0, x1, y1 per pair): the reference multiplies float table entries
+__constant__ __attribute__((aligned(16))) float c_pattern_f[1024] = MSLAM_ORB_PATTERN_INIT;
 
 // cv::fastAtan2 (OpenCV core, atan_f32), degrees in [0, 360)
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -75,108 +72,231 @@ __device__ __forceinline__ float util_sin(float v)
     return util_cos(__fsub_rn(PI_2, v));
 }
 
+constexpr int kPatchR = 19;               // sample radius of the rotated pattern (orb_patch_radius_)
+constexpr int kPatchRows = 2 * kPatchR + 1; // 39
+constexpr int kPatchDw = 11;              // 44 aligned bytes per staged row cover the 39 needed ones
+constexpr int kGroup = 64;                // keypoints per workgroup pass: one lane each in the trig phase
+constexpr int kBlocksPerFrame = 32;
+
+// 64-lane integer sum with DPP adds (VALU only, no LDS crossbar); the total lands in lane 63
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xE, true); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xC, true); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true); // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true); // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// A workgroup (4 waves) takes 64 keypoints at a time through three phases:
+//  A. moments, one wave per keypoint (16 each): the radius-15 disc is 31 rows x 8 dwords; lane t (+64k)
+//     owns dword (row t/8, column group t%8), loads it with one unaligned dword load and folds it into
+//     m10/m01 with two signed v_dot4 against per-lane weight bytes (u resp. v inside the disc, 0
+//     outside; host-built table).  Pixels are biased by -128 (xor 0x80) to fit i8; the bias cancels
+//     exactly because the disc is symmetric (sum of u = sum of v = 0).  Integer sums: order-free.
+//  B. one LANE per keypoint: fastAtan2, the f64 degree->radian product, util::cos/sin and the scalar
+//     outputs (coordinates, octave, angle, response) — the wave-uniform float work of phase C is
+//     thereby done once per keypoint instead of once per lane.
+//  C. descriptors, one wave per keypoint: the 39x39 blurred patch is staged in LDS with coalesced
+//     aligned dword loads, the 512 rotated sample points are LDS byte gathers, and four ballots are
+//     the 32 descriptor bytes.
+// Everything a wave needs about "its" keypoint is wave-uniform and kept in SGPRs (readfirstlane).
 __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
 {
-    const size_t frame = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + wave;
+    __shared__ uint32_t patch[4][kPatchRows * kPatchDw];
+    __shared__ int s_m10[kGroup], s_m01[kGroup];
+    __shared__ uint32_t s_kp[kGroup];   // packed candidate word
+    __shared__ int s_level[kGroup];
+    __shared__ float s_ca[kGroup], s_sa[kGroup];
 
-    // locate keypoint i: levels are concatenated in order (:787-808)
+    const size_t frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // levels are concatenated in order (:787-808)
     const uint32_t* sel_cnt = a.sel_cnt + frame * g.n_levels;
-    int level = -1, local = 0, total = 0;
+    int total = 0;
     for(int l = 0; l < g.n_levels; ++l)
-    {
-        const int c = (int)sel_cnt[l];
-        if(level < 0 && i < total + c)
-        {
-            level = l;
-            local = i - total;
-        }
-        total += c;
-    }
-    if(i == 0 && lane == 0)
+        total += (int)sel_cnt[l];
+    if(blockIdx.x == 0 && threadIdx.x == 0)
     {
         a.count[frame] = min(total, a.max_kp);
         if(total > a.max_kp)
             atomicOr(a.flags, kFlagKpOverflow);
     }
-    if(level < 0 || i >= a.max_kp)
-        return;
+    const int n_kp = min(total, a.max_kp);
 
-    const LevelGeom& lv = g.lv[level];
-    const uint32_t p = a.sel[(frame * g.n_levels + level) * (size_t)a.cand_cap + local];
-    const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder; // :966-967
-    const int pitch = lv.pitch;
-
-    // ---- orientation on the unblurred level
-    const uint8_t* center = a.pyr + frame * g.slab + lv.offset + (size_t)py * pitch + px;
-    int m10 = 0, m01 = 0;
-    if(lane < 31)
+    // per-lane disc weights (constant across keypoints)
+    uint32_t wu[4], wv[4];
+#pragma unroll
+    for(int k = 0; k < 4; ++k)
     {
-        const int u = lane - 15;
-        const int dv = c_umax[u < 0 ? -u : u];
-        int col = 0;
-        for(int v = -dv; v <= dv; ++v)
+        wu[k] = a.orient_w[lane + 64 * k];
+        wv[k] = a.orient_w[256 + lane + 64 * k];
+    }
+    const uint8_t* pyr = a.pyr + frame * g.slab;
+    const uint8_t* blur = a.blur + frame * g.slab;
+
+    for(int base = blockIdx.x * kGroup; base < n_kp; base += gridDim.x * kGroup)
+    {
+        const int n_here = min(kGroup, n_kp - base);
+
+        // ---- A. moments (the next keypoint's four dwords are fetched while this one is reduced)
         {
-            const int I = center[v * pitch + u];
-            col += I;
-            m01 += v * I;
+            auto locate = [&](int k, uint32_t& p, int& level) {
+                int local = base + k;
+                level = 0;
+                for(int l = 0; l < g.n_levels; ++l)
+                {
+                    const int c = (int)sel_cnt[l];
+                    if(local < c)
+                    {
+                        level = l;
+                        break;
+                    }
+                    local -= c;
+                }
+                p = __builtin_amdgcn_readfirstlane(a.sel[(frame * g.n_levels + level) * (size_t)a.cand_cap + local]);
+            };
+            auto fetch = [&](uint32_t p, int level, uint32_t (&dw)[4]) {
+                const LevelGeom& lv = g.lv[level];
+                const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder; // :966-967
+                const uint8_t* raw = pyr + lv.offset + (py - 15) * lv.pitch + (px - 15);
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    const int t = lane + 64 * q;
+                    dw[q] = t < 31 * 8 ? load_u32_unaligned(raw + (t >> 3) * lv.pitch + 4 * (t & 7)) : 0x80808080u;
+                }
+            };
+            uint32_t p = 0, dw[4];
+            int level = 0;
+            if(wave < n_here)
+            {
+                locate(wave, p, level);
+                fetch(p, level, dw);
+            }
+            for(int k = wave; k < n_here; k += 4)
+            {
+                uint32_t p_next = 0, dw_next[4] = {0, 0, 0, 0};
+                int level_next = 0;
+                if(k + 4 < n_here)
+                {
+                    locate(k + 4, p_next, level_next);
+                    fetch(p_next, level_next, dw_next);
+                }
+                int m10 = 0, m01 = 0;
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    const uint32_t x = dw[q] ^ 0x80808080u;
+                    m10 = __builtin_amdgcn_sdot4((int)x, (int)wu[q], m10, false);
+                    m01 = __builtin_amdgcn_sdot4((int)x, (int)wv[q], m01, false);
+                }
+                m10 = wave_sum_dpp(m10);
+                m01 = wave_sum_dpp(m01);
+                if(lane == 0)
+                {
+                    s_m10[k] = m10;
+                    s_m01[k] = m01;
+                    s_kp[k] = p;
+                    s_level[k] = level;
+                }
+                p = p_next;
+                level = level_next;
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                    dw[q] = dw_next[q];
+            }
         }
-        m10 = u * col;
-    }
-#pragma unroll
-    for(int o = 32; o > 0; o >>= 1)
-    {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+        __syncthreads();
 
-    // ---- rotated BRIEF on the blurred level
-    const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0); // :574
-    const float ca = util_cos(rad), sa = util_sin(rad);
-    const uint8_t* bc = a.blur + frame * g.slab + lv.offset + (size_t)py * pitch + px;
-    unsigned long long bits[4];
-#pragma unroll
-    for(int t = 0; t < 4; ++t)
-    {
-        const int pair = lane + 64 * t;
-        const char4 q = reinterpret_cast<const char4*>(c_pattern)[pair];
-        const float x0 = (float)q.x, y0 = (float)q.y, x1 = (float)q.z, y1 = (float)q.w;
-        // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-        const int v0 = bc[r0 * pitch + c0];
-        const int v1 = bc[r1 * pitch + c1];
-        bits[t] = __ballot(v0 < v1);
-    }
+        // ---- B. one lane per keypoint: angle, cos/sin, scalar outputs
+        if(threadIdx.x < n_here)
+        {
+            const int k = threadIdx.x;
+            const float angle = fast_atan2_deg((float)s_m01[k], (float)s_m10[k]);
+            const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0); // :574
+            s_ca[k] = util_cos(rad);
+            s_sa[k] = util_sin(rad);
+            const uint32_t p = s_kp[k];
+            const int level = s_level[k];
+            const float scale = g.lv[level].scale;
+            const float fx = (float)(kp_x(p) + kBorder), fy = (float)(kp_y(p) + kBorder);
+            const size_t o = frame * (size_t)a.max_kp + base + k;
+            // correct_keypoint_scale (:1166-1179): float multiply, skipped for level 0
+            a.xy[2 * o] = level == 0 ? fx : __fmul_rn(fx, scale);
+            a.xy[2 * o + 1] = level == 0 ? fy : __fmul_rn(fy, scale);
+            a.octave[o] = level;
+            a.angle[o] = angle;
+            a.response[o] = (float)kp_score(p);
+        }
+        __syncthreads();
 
-    const size_t o = frame * (size_t)a.max_kp + i;
-    if(lane < 4)
-    {
-        unsigned long long w = bits[0];
-        w = lane == 1 ? bits[1] : w;
-        w = lane == 2 ? bits[2] : w;
-        w = lane == 3 ? bits[3] : w;
-        reinterpret_cast<unsigned long long*>(a.desc + o * 32)[lane] = w;
-    }
-    if(lane == 0)
-    {
-        // correct_keypoint_scale (:1166-1179): float multiply, skipped for level 0
-        const float fx = (float)px, fy = (float)py;
-        a.xy[2 * o] = level == 0 ? fx : __fmul_rn(fx, lv.scale);
-        a.xy[2 * o + 1] = level == 0 ? fy : __fmul_rn(fy, lv.scale);
-        a.octave[o] = level;
-        a.angle[o] = angle;
-        a.response[o] = (float)kp_score(p);
+        // ---- C. descriptors
+        uint8_t* lds = reinterpret_cast<uint8_t*>(patch[wave]);
+        for(int k = wave; k < n_here; k += 4)
+        {
+            const uint32_t p = __builtin_amdgcn_readfirstlane(s_kp[k]);
+            const int level = __builtin_amdgcn_readfirstlane(s_level[k]);
+            const LevelGeom& lv = g.lv[level];
+            const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder;
+            const int pitch = lv.pitch;
+            const float ca = s_ca[k], sa = s_sa[k];
+            const int bx0 = px - kPatchR, sh = bx0 & 3;
+            const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * pitch + (bx0 - sh);
+            __builtin_amdgcn_wave_barrier(); // previous keypoint's gathers are done before the patch is overwritten
+#pragma unroll
+            for(int q = 0; q < 7; ++q)
+            {
+                const int t = lane + 64 * q;
+                if(t < kPatchRows * kPatchDw)
+                {
+                    const int r = t / kPatchDw, c = t - r * kPatchDw;
+                    patch[wave][t] = *reinterpret_cast<const uint32_t*>(bsrc + r * pitch + 4 * c);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint8_t* bc = lds + kPatchR * (kPatchDw * 4) + kPatchR + sh; // patch centre
+            unsigned long long bits[4];
+#pragma unroll
+            for(int t = 0; t < 4; ++t)
+            {
+                const float4 q = reinterpret_cast<const float4*>(c_pattern_f)[lane + 64 * t];
+                // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
+                const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(q.x, sa), __fmul_rn(q.y, ca)));
+                const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(q.x, ca), __fmul_rn(q.y, sa)));
+                const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(q.z, sa), __fmul_rn(q.w, ca)));
+                const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(q.z, ca), __fmul_rn(q.w, sa)));
+                const int v0 = bc[r0 * (kPatchDw * 4) + c0];
+                const int v1 = bc[r1 * (kPatchDw * 4) + c1];
+                bits[t] = __ballot(v0 < v1);
+            }
+            if(lane < 4)
+            {
+                unsigned long long w = bits[0];
+                w = lane == 1 ? bits[1] : w;
+                w = lane == 2 ? bits[2] : w;
+                w = lane == 3 ? bits[3] : w;
+                reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k) * 32)[lane] = w;
+            }
+        }
+        __syncthreads(); // LDS keypoint slots are reused by the next group
     }
 }
 
 void launch_describe(const Geometry& g, const DescArgs& a, int n_frames, hipStream_t s)
 {
-    dim3 grid((a.max_kp + 3) / 4, n_frames);
+    dim3 grid(kBlocksPerFrame, n_frames);
     hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, g, a);
 }
 
