@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 
 using namespace mslam;
 
@@ -275,7 +276,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
         return;
     if(c->stream)
         (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_ratio_thr, c->d_orient_w, c->d_stage,  c->d_pyr,
+    void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_rs_qbase, c->d_rs_qw, c->d_ratio_thr, c->d_orient_w, c->d_stage,  c->d_pyr,
                     c->d_blur,    c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_xy, c->d_desc, c->d_octave,
@@ -346,6 +347,46 @@ static int create_impl(mslam_hip_ctx* c)
             c->rs_y[l] = ofs.size();
             resize_table(g.lv[l - 1].h, g.lv[l].h, false, ofs, coef);
         }
+        // quad tables for k_resize_quad: 4 destination pixels share one aligned 12-byte source window
+        std::vector<uint32_t> qbase;
+        std::vector<uint4> qw;
+        c->rs_q.assign(p.n_levels, SIZE_MAX);
+        for(int l = 1; l < p.n_levels; ++l)
+        {
+            const int dw = g.lv[l].w, nq = (dw + 3) / 4;
+            const size_t x0 = c->rs_x[l], start = qbase.size();
+            bool ok = true;
+            for(int q = 0; q < nq && ok; ++q)
+            {
+                const int first = ofs[x0 + 4 * q];
+                const uint32_t base = (uint32_t)first & ~3u;
+                uint32_t wv[4];
+                for(int k = 0; k < 4; ++k)
+                {
+                    const int dx = std::min(4 * q + k, dw - 1);
+                    const int shift = ofs[x0 + dx] - (int)base;
+                    const uint32_t a0 = coef[x0 + dx] & 0xFFFF, a1 = coef[x0 + dx] >> 16;
+                    if(shift < 0 || shift > 10 || a0 > 0xFFF || a1 > 0xFFF)
+                        ok = false;
+                    wv[k] = (uint32_t)shift | (a0 << 4) | (a1 << 16);
+                }
+                qbase.push_back(base);
+                qw.push_back(make_uint4(wv[0], wv[1], wv[2], wv[3]));
+            }
+            if(ok)
+                c->rs_q[l] = start;
+            else
+            {
+                qbase.resize(start);
+                qw.resize(start);
+            }
+        }
+        qbase.push_back(0);
+        qw.push_back(make_uint4(0, 0, 0, 0));
+        HIPCHK(c, dmalloc(c->d_rs_qbase, qbase.size()));
+        HIPCHK(c, dmalloc(c->d_rs_qw, qw.size()));
+        HIPCHK(c, hipMemcpy(c->d_rs_qbase, qbase.data(), qbase.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_rs_qw, qw.data(), qw.size() * 16, hipMemcpyHostToDevice));
         ofs.push_back(0);
         coef.push_back(0);
         HIPCHK(c, dmalloc(c->d_rs_ofs, ofs.size()));
@@ -480,8 +521,14 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
     {
         StageScope t(c, "resize");
         for(int l = 1; l < g.n_levels; ++l)
-            launch_resize(c->d_pyr, g, l, c->d_rs_ofs + c->rs_x[l], c->d_rs_coef + c->rs_x[l], c->d_rs_ofs + c->rs_y[l],
-                          c->d_rs_coef + c->rs_y[l], n_frames, s);
+        {
+            if(c->rs_q[l] != SIZE_MAX)
+                launch_resize_quad(c->d_pyr, g, l, c->d_rs_qbase + c->rs_q[l], c->d_rs_qw + c->rs_q[l],
+                                   c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], n_frames, s);
+            else // windows wider than 12 bytes (very large scale factors): generic per-pixel kernel
+                launch_resize(c->d_pyr, g, l, c->d_rs_ofs + c->rs_x[l], c->d_rs_coef + c->rs_x[l],
+                              c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], n_frames, s);
+        }
     }
     {
         StageScope t(c, "fast");

@@ -68,6 +68,8 @@ enum : uint32_t
 void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int n_frames, hipStream_t s);
 void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,
                    const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s);
+void launch_resize_quad(uint8_t* d_pyr, const Geometry& g, int level, const uint32_t* d_qbase, const uint4* d_qw,
+                        const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s);
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
                  uint32_t* d_cell_kp, int ini_thr, int min_thr, int n_frames, hipStream_t s);
 struct QuadArgs

@@ -34,6 +34,9 @@ struct mslam_hip_ctx
     int32_t* d_rs_ofs = nullptr;   // resize offsets, all levels
     uint32_t* d_rs_coef = nullptr; // resize coefficients, all levels
     std::vector<size_t> rs_x, rs_y; // per-level start index into d_rs_*
+    uint32_t* d_rs_qbase = nullptr; // quad tables (k_resize_quad), all levels
+    uint4* d_rs_qw = nullptr;
+    std::vector<size_t> rs_q;       // per-level start index into the quad tables; SIZE_MAX = use the generic kernel
     int32_t* d_ratio_thr = nullptr; // [257]
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
     double ratio_cached = -1.0;
