@@ -112,7 +112,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
 // Everything a wave needs about "its" keypoint is wave-uniform and kept in SGPRs (readfirstlane).
 __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
 {
-    __shared__ uint32_t patch[4][kPatchRows * kPatchDw];
+    __shared__ uint32_t patch[4][2][kPatchRows * kPatchDw];
     __shared__ int s_m10[kGroup], s_m01[kGroup];
     __shared__ uint32_t s_kp[kGroup];   // packed candidate word
     __shared__ int s_level[kGroup];
@@ -150,25 +150,30 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     {
         const int n_here = min(kGroup, n_kp - base);
 
-        // ---- A. moments (the next keypoint's four dwords are fetched while this one is reduced)
+        // ---- 0. one lane per keypoint: which level, which candidate word
+        if(threadIdx.x < n_here)
         {
-            auto locate = [&](int k, uint32_t& p, int& level) {
-                int local = base + k;
-                level = 0;
-                for(int l = 0; l < g.n_levels; ++l)
+            int local = base + threadIdx.x, level = 0;
+            for(int l = 0; l < g.n_levels; ++l)
+            {
+                const int c = (int)sel_cnt[l];
+                if(local < c)
                 {
-                    const int c = (int)sel_cnt[l];
-                    if(local < c)
-                    {
-                        level = l;
-                        break;
-                    }
-                    local -= c;
+                    level = l;
+                    break;
                 }
-                p = __builtin_amdgcn_readfirstlane(a.sel[(frame * g.n_levels + level) * (size_t)a.cand_cap + local]);
-            };
-            auto fetch = [&](uint32_t p, int level, uint32_t (&dw)[4]) {
-                const LevelGeom& lv = g.lv[level];
+                local -= c;
+            }
+            s_kp[threadIdx.x] = a.sel[(frame * g.n_levels + level) * (size_t)a.cand_cap + local];
+            s_level[threadIdx.x] = level;
+        }
+        __syncthreads();
+
+        // ---- A. moments; two keypoints per wave are in flight at a time
+        {
+            auto fetch = [&](int k, uint32_t (&dw)[4]) {
+                const uint32_t p = __builtin_amdgcn_readfirstlane(s_kp[k]);
+                const LevelGeom& lv = g.lv[__builtin_amdgcn_readfirstlane(s_level[k])];
                 const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder; // :966-967
                 const uint8_t* raw = pyr + lv.offset + (py - 15) * lv.pitch + (px - 15);
 #pragma unroll
@@ -178,22 +183,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     dw[q] = t < 31 * 8 ? load_u32_unaligned(raw + (t >> 3) * lv.pitch + 4 * (t & 7)) : 0x80808080u;
                 }
             };
-            uint32_t p = 0, dw[4];
-            int level = 0;
-            if(wave < n_here)
-            {
-                locate(wave, p, level);
-                fetch(p, level, dw);
-            }
-            for(int k = wave; k < n_here; k += 4)
-            {
-                uint32_t p_next = 0, dw_next[4] = {0, 0, 0, 0};
-                int level_next = 0;
-                if(k + 4 < n_here)
-                {
-                    locate(k + 4, p_next, level_next);
-                    fetch(p_next, level_next, dw_next);
-                }
+            auto reduce = [&](int k, const uint32_t (&dw)[4]) {
                 int m10 = 0, m01 = 0;
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
@@ -208,14 +198,17 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 {
                     s_m10[k] = m10;
                     s_m01[k] = m01;
-                    s_kp[k] = p;
-                    s_level[k] = level;
                 }
-                p = p_next;
-                level = level_next;
-#pragma unroll
-                for(int q = 0; q < 4; ++q)
-                    dw[q] = dw_next[q];
+            };
+            for(int k = wave; k < n_here; k += 8)
+            {
+                uint32_t d0[4], d1[4];
+                fetch(k, d0);
+                if(k + 4 < n_here)
+                    fetch(k + 4, d1);
+                reduce(k, d0);
+                if(k + 4 < n_here)
+                    reduce(k + 4, d1);
             }
         }
         __syncthreads();
@@ -242,52 +235,65 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
         }
         __syncthreads();
 
-        // ---- C. descriptors
-        uint8_t* lds = reinterpret_cast<uint8_t*>(patch[wave]);
-        for(int k = wave; k < n_here; k += 4)
+        // ---- C. descriptors; two keypoints per wave are in flight at a time
         {
-            const uint32_t p = __builtin_amdgcn_readfirstlane(s_kp[k]);
-            const int level = __builtin_amdgcn_readfirstlane(s_level[k]);
-            const LevelGeom& lv = g.lv[level];
-            const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder;
-            const int pitch = lv.pitch;
-            const float ca = s_ca[k], sa = s_sa[k];
-            const int bx0 = px - kPatchR, sh = bx0 & 3;
-            const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * pitch + (bx0 - sh);
-            __builtin_amdgcn_wave_barrier(); // previous keypoint's gathers are done before the patch is overwritten
+            auto stage = [&](int k, int buf, int& sh_out) {
+                const uint32_t p = __builtin_amdgcn_readfirstlane(s_kp[k]);
+                const LevelGeom& lv = g.lv[__builtin_amdgcn_readfirstlane(s_level[k])];
+                const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder;
+                const int bx0 = px - kPatchR, sh = bx0 & 3;
+                sh_out = sh;
+                const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * lv.pitch + (bx0 - sh);
 #pragma unroll
-            for(int q = 0; q < 7; ++q)
-            {
-                const int t = lane + 64 * q;
-                if(t < kPatchRows * kPatchDw)
+                for(int q = 0; q < 7; ++q)
                 {
-                    const int r = t / kPatchDw, c = t - r * kPatchDw;
-                    patch[wave][t] = *reinterpret_cast<const uint32_t*>(bsrc + r * pitch + 4 * c);
+                    const int t = lane + 64 * q;
+                    if(t < kPatchRows * kPatchDw)
+                    {
+                        const int r = t / kPatchDw, c = t - r * kPatchDw;
+                        patch[wave][buf][t] = *reinterpret_cast<const uint32_t*>(bsrc + r * lv.pitch + 4 * c);
+                    }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint8_t* bc = lds + kPatchR * (kPatchDw * 4) + kPatchR + sh; // patch centre
-            unsigned long long bits[4];
+            };
+            auto describe = [&](int k, int buf, int sh) {
+                const float ca = s_ca[k], sa = s_sa[k];
+                const uint8_t* bc =
+                    reinterpret_cast<const uint8_t*>(patch[wave][buf]) + kPatchR * (kPatchDw * 4) + kPatchR + sh; // centre
+                unsigned long long bits[4];
 #pragma unroll
-            for(int t = 0; t < 4; ++t)
+                for(int t = 0; t < 4; ++t)
+                {
+                    const float4 q = reinterpret_cast<const float4*>(c_pattern_f)[lane + 64 * t];
+                    // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
+                    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(q.x, sa), __fmul_rn(q.y, ca)));
+                    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(q.x, ca), __fmul_rn(q.y, sa)));
+                    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(q.z, sa), __fmul_rn(q.w, ca)));
+                    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(q.z, ca), __fmul_rn(q.w, sa)));
+                    const int v0 = bc[r0 * (kPatchDw * 4) + c0];
+                    const int v1 = bc[r1 * (kPatchDw * 4) + c1];
+                    bits[t] = __ballot(v0 < v1);
+                }
+                if(lane < 4)
+                {
+                    unsigned long long w = bits[0];
+                    w = lane == 1 ? bits[1] : w;
+                    w = lane == 2 ? bits[2] : w;
+                    w = lane == 3 ? bits[3] : w;
+                    reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k) * 32)[lane] = w;
+                }
+            };
+            for(int k = wave; k < n_here; k += 8)
             {
-                const float4 q = reinterpret_cast<const float4*>(c_pattern_f)[lane + 64 * t];
-                // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
-                const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(q.x, sa), __fmul_rn(q.y, ca)));
-                const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(q.x, ca), __fmul_rn(q.y, sa)));
-                const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(q.z, sa), __fmul_rn(q.w, ca)));
-                const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(q.z, ca), __fmul_rn(q.w, sa)));
-                const int v0 = bc[r0 * (kPatchDw * 4) + c0];
-                const int v1 = bc[r1 * (kPatchDw * 4) + c1];
-                bits[t] = __ballot(v0 < v1);
-            }
-            if(lane < 4)
-            {
-                unsigned long long w = bits[0];
-                w = lane == 1 ? bits[1] : w;
-                w = lane == 2 ? bits[2] : w;
-                w = lane == 3 ? bits[3] : w;
-                reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k) * 32)[lane] = w;
+                int sh0 = 0, sh1 = 0;
+                const bool two = k + 4 < n_here;
+                __builtin_amdgcn_wave_barrier(); // the previous pair's gathers are done before the patches are overwritten
+                stage(k, 0, sh0);
+                if(two)
+                    stage(k + 4, 1, sh1);
+                __builtin_amdgcn_wave_barrier();
+                describe(k, 0, sh0);
+                if(two)
+                    describe(k + 4, 1, sh1);
             }
         }
         __syncthreads(); // LDS keypoint slots are reused by the next group
