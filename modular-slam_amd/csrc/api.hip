@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 
 using namespace mslam;
@@ -290,6 +291,18 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
+    if(c->ev_fork)
+        (void)hipEventDestroy(c->ev_fork);
+    for(int k = 0; k < 4; ++k)
+    {
+        if(c->ev_join[k])
+            (void)hipEventDestroy(c->ev_join[k]);
+        if(c->side[k])
+        {
+            (void)hipStreamSynchronize(c->side[k]);
+            (void)hipStreamDestroy(c->side[k]);
+        }
+    }
     if(c->bow)
         bow_destroy(c->bow);
     if(c->own_stream && c->stream)
@@ -332,6 +345,16 @@ static int create_impl(mslam_hip_ctx* c)
         c->own_stream = true;
     }
 
+    {
+        const char* e = getenv("MSLAM_HIP_STREAMS");
+        c->n_side = e ? std::max(1, std::min(atoi(e), 4)) : 1; // measured: 2 / 4 chunks are 2 % / 10 % slower than 1
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for(int k = 0; k < c->n_side; ++k)
+        {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+        }
+    }
     // tables
     HIPCHK(c, dmalloc(c->d_cells, c->cells.size()));
     HIPCHK(c, hipMemcpy(c->d_cells, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
@@ -470,6 +493,8 @@ int mslam_hip_create(const mslam_hip_params* p, mslam_hip_ctx** out)
     return MSLAM_HIP_OK;
 }
 
+constexpr int kMinChunk = 8; // do not cut batches into chunks smaller than this many frames
+
 static int check_flags(mslam_hip_ctx* c)
 {
     uint32_t f = 0;
@@ -514,53 +539,73 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
         HIPCHK(c, hipMemcpyAsync(c->d_count, c->d_count + last, 4, hipMemcpyDeviceToDevice, s));
         c->have_prev = true;
     }
+    // Frames are independent until the matcher, so the batch is cut into chunks that run the same
+    // kernel sequence on separate HIP streams: the latency-bound kernels of one chunk (quadtree, the
+    // tails of every launch) overlap the throughput-bound kernels of the other.  With profiling on,
+    // everything runs on the context's stream so that the per-stage events are meaningful.
+    const int n_chunks = (c->profiling || n_frames < 2 * kMinChunk) ? 1 : std::min<int>(c->n_side, n_frames / kMinChunk);
+    if(n_chunks > 1)
+        HIPCHK(c, hipEventRecord(c->ev_fork, s));
+    for(int k = 0; k < n_chunks; ++k)
     {
-        StageScope t(c, "gray");
-        launch_gray(d_bgr, c->d_pyr, g, n_frames, s);
-    }
-    {
-        StageScope t(c, "resize");
-        for(int l = 1; l < g.n_levels; ++l)
+        const int f0 = (int)((long long)n_frames * k / n_chunks), f1 = (int)((long long)n_frames * (k + 1) / n_chunks);
+        const int nf = f1 - f0;
+        hipStream_t cs = n_chunks > 1 ? c->side[k] : s;
+        if(n_chunks > 1)
+            HIPCHK(c, hipStreamWaitEvent(cs, c->ev_fork, 0));
         {
-            if(c->rs_q[l] != SIZE_MAX)
-                launch_resize_quad(c->d_pyr, g, l, c->d_rs_qbase + c->rs_q[l], c->d_rs_qw + c->rs_q[l],
-                                   c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], n_frames, s);
-            else // windows wider than 12 bytes (very large scale factors): generic per-pixel kernel
-                launch_resize(c->d_pyr, g, l, c->d_rs_ofs + c->rs_x[l], c->d_rs_coef + c->rs_x[l],
-                              c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], n_frames, s);
+            StageScope t(c, "gray");
+            launch_gray(d_bgr, c->d_pyr, g, f0, nf, cs);
         }
-    }
-    {
-        StageScope t(c, "fast");
-        launch_fast(c->d_pyr, g, c->d_cells, c->d_cell_cnt, c->d_cell_kp, c->p.ini_fast_thr, c->p.min_fast_thr,
-                    n_frames, s);
-    }
-    {
-        StageScope t(c, "quadtree");
-        launch_quadtree(g, c->quad, n_frames, s);
-    }
-    {
-        StageScope t(c, "blur");
-        launch_blur(c->d_pyr, c->d_blur, g, n_frames, s);
-    }
-    {
-        StageScope t(c, "describe");
-        DescArgs a{};
-        a.pyr = c->d_pyr;
-        a.blur = c->d_blur;
-        a.sel = c->quad.sel;
-        a.sel_cnt = c->quad.sel_cnt;
-        a.orient_w = c->d_orient_w;
-        a.cand_cap = c->p.max_candidates;
-        a.max_kp = c->p.max_keypoints;
-        a.xy = c->d_xy + K * 2;
-        a.desc = c->d_desc + K * 32;
-        a.octave = c->d_octave + K;
-        a.angle = c->d_angle + K;
-        a.response = c->d_response + K;
-        a.count = c->d_count + 1;
-        a.flags = c->d_flags;
-        launch_describe(g, a, n_frames, s);
+        {
+            StageScope t(c, "resize");
+            for(int l = 1; l < g.n_levels; ++l)
+            {
+                if(c->rs_q[l] != SIZE_MAX)
+                    launch_resize_quad(c->d_pyr, g, l, c->d_rs_qbase + c->rs_q[l], c->d_rs_qw + c->rs_q[l],
+                                       c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], f0, nf, cs);
+                else // windows wider than 12 bytes (very large scale factors): generic per-pixel kernel
+                    launch_resize(c->d_pyr, g, l, c->d_rs_ofs + c->rs_x[l], c->d_rs_coef + c->rs_x[l],
+                                  c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], f0, nf, cs);
+            }
+        }
+        {
+            StageScope t(c, "fast");
+            launch_fast(c->d_pyr, g, c->d_cells, c->d_cell_cnt, c->d_cell_kp, c->p.ini_fast_thr, c->p.min_fast_thr, f0,
+                        nf, cs);
+        }
+        {
+            StageScope t(c, "quadtree");
+            launch_quadtree(g, c->quad, f0, nf, cs);
+        }
+        {
+            StageScope t(c, "blur");
+            launch_blur(c->d_pyr, c->d_blur, g, f0, nf, cs);
+        }
+        {
+            StageScope t(c, "describe");
+            DescArgs a{};
+            a.pyr = c->d_pyr;
+            a.blur = c->d_blur;
+            a.sel = c->quad.sel;
+            a.sel_cnt = c->quad.sel_cnt;
+            a.orient_w = c->d_orient_w;
+            a.cand_cap = c->p.max_candidates;
+            a.max_kp = c->p.max_keypoints;
+            a.xy = c->d_xy + K * 2;
+            a.desc = c->d_desc + K * 32;
+            a.octave = c->d_octave + K;
+            a.angle = c->d_angle + K;
+            a.response = c->d_response + K;
+            a.count = c->d_count + 1;
+            a.flags = c->d_flags;
+            launch_describe(g, a, f0, nf, cs);
+        }
+        if(n_chunks > 1)
+        {
+            HIPCHK(c, hipEventRecord(c->ev_join[k], cs));
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[k], 0));
+        }
     }
     HIPCHK(c, hipGetLastError());
     c->n_last = n_frames;

@@ -36,6 +36,7 @@ struct Geometry
     int n_levels;
     int W, H;
     int n_cells, n_tiles;
+    int frame0;    // first frame this launch works on (blockIdx is relative to it)
     unsigned slab; // bytes per frame (all levels)
     LevelGeom lv[kMaxLevels];
 };
@@ -65,13 +66,14 @@ enum : uint32_t
 };
 
 // ---- kernel launchers (each enqueues on `s`, no synchronisation) ----------------------------------
-void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int n_frames, hipStream_t s);
+// every launcher works on frames [frame0, frame0 + n_frames) of the batch buffers
+void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int frame0, int n_frames, hipStream_t s);
 void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,
-                   const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s);
+                   const int32_t* d_yofs, const uint32_t* d_ycoef, int frame0, int n_frames, hipStream_t s);
 void launch_resize_quad(uint8_t* d_pyr, const Geometry& g, int level, const uint32_t* d_qbase, const uint4* d_qw,
-                        const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s);
+                        const int32_t* d_yofs, const uint32_t* d_ycoef, int frame0, int n_frames, hipStream_t s);
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
-                 uint32_t* d_cell_kp, int ini_thr, int min_thr, int n_frames, hipStream_t s);
+                 uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s);
 struct QuadArgs
 {
     const uint32_t* cell_cnt; // [B][n_cells]
@@ -93,8 +95,8 @@ struct QuadArgs
     int cand_cap;
     unsigned min_size;
 };
-void launch_quadtree(const Geometry& g, const QuadArgs& a, int n_frames, hipStream_t s);
-void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int n_frames, hipStream_t s);
+void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_frames, hipStream_t s);
+void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int frame0, int n_frames, hipStream_t s);
 struct DescArgs
 {
     const uint8_t* pyr;
@@ -112,7 +114,7 @@ struct DescArgs
     int32_t* count;
     uint32_t* flags;
 };
-void launch_describe(const Geometry& g, const DescArgs& a, int n_frames, hipStream_t s);
+void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_frames, hipStream_t s);
 
 // knn-2 Hamming match for `n_pairs` independent (from, to) pairs.  Descriptor sets are addressed as
 // base + pair_index * stride; counts come from device arrays (or fixed values when the pointer is null).

@@ -24,6 +24,10 @@ struct mslam_hip_ctx
     mslam::Geometry geom{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // side streams for chunked batches (see mslam_hip_detect_batch_dev)
+    int n_side = 2;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
 
     // host copies of the tables

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const int x0 = (sidx - band * lv.bsx) * 4;
     const int y0 = band * kBlurRows;
     const int w = lv.w, h = lv.h, pitch = lv.pitch;
-    const size_t frame = blockIdx.y;
+    const size_t frame = blockIdx.y + g.frame0;
     const uint8_t* src = pyr + frame * g.slab + lv.offset;
     uint8_t* dst = blur + frame * g.slab + lv.offset;
 
@@ -157,10 +157,12 @@ void set_blur_taps(const int* t)
         g_taps.t[i] = t[i];
 }
 
-void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int n_frames, hipStream_t s)
+void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int frame0, int n_frames, hipStream_t s)
 {
     dim3 grid((g.n_tiles + 255) / 256, n_frames);
-    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, d_pyr, d_blur, g, g_taps);
+    Geometry gg = g;
+    gg.frame0 = frame0;
+    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, d_pyr, d_blur, gg, g_taps);
 }
 
 } // namespace mslam

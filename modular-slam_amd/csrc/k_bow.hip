@@ -51,6 +51,8 @@ struct BowState
     int32_t* d_rn = nullptr;        // [RP]
     long long next_id = 0;
     // scoring outputs
+    double* d_contrib = nullptr;    // [B+1][cap][R] matched terms, ascending word order, entry index fastest
+    int32_t* d_match_cnt = nullptr; // [B+1][R]
     double* d_scores = nullptr;     // [B+1][R]   score against entry (id_t - 1 - j), -1 when absent / no common word
     int32_t* d_best_entry = nullptr; // [B+1]
     double* d_best_score = nullptr;
@@ -62,7 +64,7 @@ static void bow_free(BowState* b)
 {
     void* bufs[] = {b->d_desc,   b->d_first,   b->d_nchild, b->d_word,   b->d_weight,     b->d_fword,      b->d_fweight,
                     b->d_bwords, b->d_bvalues, b->d_bn,     b->d_rwords, b->d_rvalues,    b->d_rn,         b->d_scores,
-                    b->d_best_entry, b->d_best_score, b->d_hdesc};
+                    b->d_best_entry, b->d_best_score, b->d_hdesc, b->d_contrib, b->d_match_cnt};
     for(void* p : bufs)
         if(p)
             (void)hipFree(p);
@@ -262,76 +264,163 @@ __global__ __launch_bounds__(256) void k_bow_commit(const uint32_t* __restrict__
         rn[slot] = n;
 }
 
+constexpr int kScoreWaves = 4; // database entries scored per workgroup (one per wave)
+
 // L1Scoring::score of query vector `qslot + blockIdx.y` against the window of database entries that
-// precede it.  One thread per (query, entry); the workgroup then picks the best entry.
-__global__ void k_bow_score(const uint32_t* __restrict__ bwords, const double* __restrict__ bvalues,
-                            const int32_t* __restrict__ bn, int qslot, int cap, const uint32_t* __restrict__ rwords,
-                            const double* __restrict__ rvalues, const int32_t* __restrict__ rn, long long base_id,
-                            int per_frame_id, int R, int RP, double* __restrict__ scores, int32_t* __restrict__ best_entry,
-                            double* __restrict__ best_score)
+// precede it.  The query's words go into an LDS hash table once per workgroup; each wave then streams
+// one database entry through it (coalesced loads, one probe per element).  The per-element terms
+// |v-w|-|v|-|w| are exact and order-free; their SUM must follow the reference's ascending-word order,
+// so every 64-element chunk adds its matches in lane order (ballot + readlane), chunk after chunk.
+__global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
+    const uint32_t* __restrict__ bwords, const double* __restrict__ bvalues, const int32_t* __restrict__ bn, int qslot,
+    int cap, const uint32_t* __restrict__ rwords, const double* __restrict__ rvalues, const int32_t* __restrict__ rn,
+    long long base_id, int per_frame_id, int R, int RP, int slots, double* __restrict__ contrib,
+    int32_t* __restrict__ match_cnt)
 {
-    extern __shared__ double red[]; // blockDim.x scores then ids
+    extern __shared__ uint32_t sm[]; // [slots] hash table of (index + 1), then [cap] query words
+    uint32_t* table = sm;
+    uint32_t* qw = sm + slots;
+
     const int t = blockIdx.y;
-    const int j = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = blockIdx.x * kScoreWaves + wave;
     const long long id_t = base_id + (per_frame_id ? t : 0); // entries with id < id_t are visible
+    if((long long)blockIdx.x * kScoreWaves >= id_t || blockIdx.x * kScoreWaves >= R)
+    {
+        // nothing visible in this group: mark absent
+        if(lane == 0 && j < R)
+            match_cnt[(size_t)(qslot + t) * R + j] = -1;
+        return;
+    }
+    const uint32_t* w1 = bwords + (size_t)(qslot + t) * cap;
+    const double* v1 = bvalues + (size_t)(qslot + t) * cap;
+    const int n1 = bn[qslot + t];
+    const uint32_t hmask = (uint32_t)slots - 1;
+
+    for(int i = tid; i < slots; i += 64 * kScoreWaves)
+        table[i] = 0;
+    for(int i = tid; i < n1; i += 64 * kScoreWaves)
+        qw[i] = w1[i];
+    __syncthreads();
+    for(int i = tid; i < n1; i += 64 * kScoreWaves)
+    {
+        uint32_t h = (qw[i] * 2654435761u) >> 7 & hmask;
+        while(atomicCAS(&table[h], 0u, (uint32_t)i + 1u) != 0u)
+            h = (h + 1) & hmask;
+    }
+    __syncthreads();
+
     const long long e_id = id_t - 1 - j;
-    double score = -1.0;
-    if(j < R && e_id >= 0)
+    if(j >= R)
+        return;
+    if(e_id >= 0)
     {
         const int slot = (int)(e_id % RP);
-        const uint32_t* w1 = bwords + (size_t)(qslot + t) * cap;
-        const double* v1 = bvalues + (size_t)(qslot + t) * cap;
-        const int n1 = bn[qslot + t];
         const uint32_t* w2 = rwords + (size_t)slot * cap;
         const double* v2 = rvalues + (size_t)slot * cap;
         const int n2 = rn[slot];
-        int a = 0, b = 0;
-        double s = 0;
-        bool common = false;
-        while(a < n1 && b < n2)
+        // matched terms are written, in ascending word order, to contrib[t][k][j] (entry index fastest)
+        double* out = contrib + (size_t)(qslot + t) * cap * R + j;
+        uint32_t n_match = 0;
+        for(int base = 0; base < n2; base += 64)
         {
-            const uint32_t x = w1[a], y = w2[b];
-            if(x == y)
+            const int i = base + lane;
+            double c = 0;
+            bool found = false;
+            if(i < n2)
             {
-                const double vi = v1[a], wi = v2[b];
-                s += fabs(vi - wi) - fabs(vi) - fabs(wi);
-                common = true;
-                ++a, ++b;
+                const uint32_t word = w2[i];
+                uint32_t h = (word * 2654435761u) >> 7 & hmask;
+                for(;;)
+                {
+                    const uint32_t e = table[h];
+                    if(e == 0)
+                        break;
+                    if(qw[e - 1] == word)
+                    {
+                        const double vi = v1[e - 1], wi = v2[i];
+                        c = fabs(vi - wi) - fabs(vi) - fabs(wi);
+                        found = true;
+                        break;
+                    }
+                    h = (h + 1) & hmask;
+                }
             }
-            else if(x < y)
-                ++a;
-            else
-                ++b;
+            const unsigned long long m = __ballot(found);
+            if(found)
+                out[(size_t)(n_match + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) * R] = c;
+            n_match += (uint32_t)__popcll(m);
         }
-        if(common) // Database::queryL1 only reports entries sharing a word with the query
-            score = -s / 2.0;
+        if(lane == 0)
+            match_cnt[(size_t)(qslot + t) * R + j] = (int32_t)n_match;
+        return;
     }
-    if(j < R)
-        scores[(size_t)(qslot + t) * R + j] = score;
-    // best = highest score, ties to the lower entry id (= the higher j)
-    double* rs = red;
-    long long* rid = reinterpret_cast<long long*>(red + blockDim.x);
-    rs[j] = score;
-    rid[j] = score >= 0 ? e_id : -1;
-    __syncthreads();
-    for(int o = blockDim.x >> 1; o > 0; o >>= 1)
+    if(lane == 0)
+        match_cnt[(size_t)(qslot + t) * R + j] = -1; // entry does not exist
+}
+
+// Sequential, ascending-word-order sum of the matched terms: one LANE per (query, entry), so the 64
+// dependent f64 chains of a query run side by side; reads are coalesced (entry index is fastest).
+__global__ __launch_bounds__(64) void k_bow_sum(const double* __restrict__ contrib, const int32_t* __restrict__ match_cnt,
+                                                int qslot, int cap, int R, double* __restrict__ scores)
+{
+    const int t = blockIdx.y;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if(j >= R)
+        return;
+    const int n = match_cnt[(size_t)(qslot + t) * R + j];
+    const double* in = contrib + (size_t)(qslot + t) * cap * R + j;
+    double s = 0;
+    int k = 0;
+    for(; k + 32 <= n; k += 32) // 32 loads in flight, then the 32 dependent adds in order
     {
-        if(j < o)
+        double v[32];
+#pragma unroll
+        for(int u = 0; u < 32; ++u)
+            v[u] = in[(size_t)(k + u) * R];
+#pragma unroll
+        for(int u = 0; u < 32; ++u)
+            s += v[u];
+    }
+    for(; k < n; ++k)
+        s += in[(size_t)k * R];
+    // Database::queryL1 only reports entries sharing a word with the query
+    scores[(size_t)(qslot + t) * R + j] = n > 0 ? -s / 2.0 : -1.0;
+}
+// best entry per query: highest score, ties to the lower entry id (= the higher j)
+__global__ __launch_bounds__(64) void k_bow_best(const double* __restrict__ scores, int qslot, long long base_id,
+                                                 int per_frame_id, int R, int32_t* __restrict__ best_entry,
+                                                 double* __restrict__ best_score)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const long long id_t = base_id + (per_frame_id ? t : 0);
+    double bs = -1.0;
+    long long bi = -1;
+    for(int j = lane; j < R; j += 64)
+    {
+        const double s = scores[(size_t)(qslot + t) * R + j];
+        const long long e = id_t - 1 - j;
+        if(s >= 0 && e >= 0 && (bi < 0 || s > bs || (s == bs && e < bi)))
         {
-            const double s2 = rs[j + o];
-            const long long i2 = rid[j + o];
-            if(i2 >= 0 && (rid[j] < 0 || s2 > rs[j] || (s2 == rs[j] && i2 < rid[j])))
-            {
-                rs[j] = s2;
-                rid[j] = i2;
-            }
+            bs = s;
+            bi = e;
         }
-        __syncthreads();
     }
-    if(j == 0)
+    for(int o = 32; o > 0; o >>= 1)
     {
-        best_entry[qslot + t] = (int32_t)rid[0];
-        best_score[qslot + t] = rid[0] >= 0 ? rs[0] : 0.0;
+        const double s2 = __shfl_xor(bs, o);
+        const long long i2 = __shfl_xor(bi, o);
+        if(i2 >= 0 && (bi < 0 || s2 > bs || (s2 == bs && i2 < bi)))
+        {
+            bs = s2;
+            bi = i2;
+        }
+    }
+    if(lane == 0)
+    {
+        best_entry[qslot + t] = (int32_t)bi;
+        best_score[qslot + t] = bi >= 0 ? bs : 0.0;
     }
 }
 
@@ -571,6 +660,8 @@ static int bow_load_impl(mslam_hip_ctx* c, const void* blob, size_t size)
     BALLOC(b->d_rvalues, RP * cap);
     BALLOC(b->d_rn, RP);
     BALLOC(b->d_scores, (B + 1) * (size_t)b->R);
+    BALLOC(b->d_contrib, (B + 1) * cap * (size_t)b->R);
+    BALLOC(b->d_match_cnt, (B + 1) * (size_t)b->R);
     BALLOC(b->d_best_entry, B + 1);
     BALLOC(b->d_best_score, B + 1);
     BALLOC(b->d_hdesc, cap * 32);
@@ -625,12 +716,21 @@ static int bow_score_dev(mslam_hip_ctx* c, int qslot, int n_frames, long long ba
 {
     BowState* b = c->bow;
     StageScope t3(c, "bow_score");
-    int threads = 64;
-    while(threads < b->R)
-        threads <<= 1;
-    hipLaunchKernelGGL(k_bow_score, dim3(1, n_frames), dim3(threads), (size_t)threads * 16, c->stream, b->d_bwords,
-                       b->d_bvalues, b->d_bn, qslot, b->cap, b->d_rwords, b->d_rvalues, b->d_rn, base_id, per_frame_id,
-                       b->R, b->RP, b->d_scores, b->d_best_entry, b->d_best_score);
+    int slots = 1024;
+    while(slots < 2 * b->cap)
+        slots <<= 1;
+    const size_t lds = (size_t)(slots + b->cap) * 4;
+    if(lds > 48 * 1024)
+        BHIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_score),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((b->R + kScoreWaves - 1) / kScoreWaves, n_frames);
+    hipLaunchKernelGGL(k_bow_score, grid, dim3(64 * kScoreWaves), lds, c->stream, b->d_bwords, b->d_bvalues, b->d_bn, qslot,
+                       b->cap, b->d_rwords, b->d_rvalues, b->d_rn, base_id, per_frame_id, b->R, b->RP, slots, b->d_contrib,
+                       b->d_match_cnt);
+    hipLaunchKernelGGL(k_bow_sum, dim3((b->R + 63) / 64, n_frames), dim3(64), 0, c->stream, b->d_contrib, b->d_match_cnt,
+                       qslot, b->cap, b->R, b->d_scores);
+    hipLaunchKernelGGL(k_bow_best, dim3(n_frames), dim3(64), 0, c->stream, b->d_scores, qslot, base_id, per_frame_id, b->R,
+                       b->d_best_entry, b->d_best_score);
     BHIPCHK(c, hipGetLastError());
     return MSLAM_HIP_OK;
 }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     __shared__ int s_level[kGroup];
     __shared__ float s_ca[kGroup], s_sa[kGroup];
 
-    const size_t frame = blockIdx.y;
+    const size_t frame = blockIdx.y + g.frame0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -300,10 +300,12 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     }
 }
 
-void launch_describe(const Geometry& g, const DescArgs& a, int n_frames, hipStream_t s)
+void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_frames, hipStream_t s)
 {
     dim3 grid(kBlocksPerFrame, n_frames);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, g, a);
+    Geometry gg = g;
+    gg.frame0 = frame0;
+    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, gg, a);
 }
 
 } // namespace mslam

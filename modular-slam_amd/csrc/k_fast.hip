@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     __shared__ uint32_t n_cand;
 
     const int cell_id = blockIdx.x;
-    const size_t frame = blockIdx.y;
+    const size_t frame = blockIdx.y + g.frame0;
     const CellDesc c = cells[cell_id];
     const LevelGeom& lv = g.lv[c.level];
     const int cw = c.cw, ch = c.ch;
@@ -221,10 +221,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 }
 
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
-                 uint32_t* d_cell_kp, int ini_thr, int min_thr, int n_frames, hipStream_t s)
+                 uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s)
 {
     dim3 grid(g.n_cells, n_frames);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, d_pyr, g, d_cells, d_cell_cnt, d_cell_kp, ini_thr, min_thr);
+    Geometry gg = g;
+    gg.frame0 = frame0;
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, d_pyr, gg, d_cells, d_cell_cnt, d_cell_kp, ini_thr, min_thr);
 }
 
 } // namespace mslam

@@ -22,13 +22,13 @@ __device__ __forceinline__ uint32_t gray_px(uint32_t c0, uint32_t c1, uint32_t c
 
 // W % 4 == 0: one lane converts 4 pixels = 12 source bytes (3 aligned dwords) -> 1 dword.
 __global__ __launch_bounds__(256) void k_gray4(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ pyr, int W, int H,
-                                               int pitch, unsigned slab)
+                                               int pitch, unsigned slab, int frame0)
 {
     const int quad = blockIdx.x * 256 + threadIdx.x;
     const int n_quads = (W * H) >> 2;
     if(quad >= n_quads)
         return;
-    const size_t frame = blockIdx.y;
+    const size_t frame = blockIdx.y + frame0;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(bgr + frame * (size_t)W * H * 3) + (size_t)quad * 3;
     const uint32_t a = src[0], b = src[1], c = src[2];
     // bytes: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3   (little endian)
@@ -43,30 +43,30 @@ __global__ __launch_bounds__(256) void k_gray4(const uint8_t* __restrict__ bgr, 
 
 // generic width: one pixel per lane
 __global__ __launch_bounds__(256) void k_gray1(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ pyr, int W, int H,
-                                               int pitch, unsigned slab)
+                                               int pitch, unsigned slab, int frame0)
 {
     const int px = blockIdx.x * 256 + threadIdx.x;
     if(px >= W * H)
         return;
-    const size_t frame = blockIdx.y;
+    const size_t frame = blockIdx.y + frame0;
     const uint8_t* src = bgr + frame * (size_t)W * H * 3 + (size_t)px * 3;
     const int y = px / W, x = px - y * W;
     pyr[frame * slab + (size_t)y * pitch + x] = (uint8_t)gray_px(src[0], src[1], src[2]);
 }
 
-void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int n_frames, hipStream_t s)
+void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int frame0, int n_frames, hipStream_t s)
 {
     const LevelGeom& l0 = g.lv[0];
     if((g.W & 3) == 0)
     {
         const int n_quads = (g.W * g.H) >> 2;
         dim3 grid((n_quads + 255) / 256, n_frames);
-        hipLaunchKernelGGL(k_gray4, grid, dim3(256), 0, s, d_bgr, d_pyr + l0.offset, g.W, g.H, l0.pitch, g.slab);
+        hipLaunchKernelGGL(k_gray4, grid, dim3(256), 0, s, d_bgr, d_pyr + l0.offset, g.W, g.H, l0.pitch, g.slab, frame0);
     }
     else
     {
         dim3 grid((g.W * g.H + 255) / 256, n_frames);
-        hipLaunchKernelGGL(k_gray1, grid, dim3(256), 0, s, d_bgr, d_pyr + l0.offset, g.W, g.H, l0.pitch, g.slab);
+        hipLaunchKernelGGL(k_gray1, grid, dim3(256), 0, s, d_bgr, d_pyr + l0.offset, g.W, g.H, l0.pitch, g.slab, frame0);
     }
 }
 
@@ -75,13 +75,14 @@ void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int n_
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsigned slab, int src_off, int sw, int sh,
                                                 int spitch, int dst_off, int dw, int dh, int dpitch,
                                                 const int32_t* __restrict__ xofs, const uint32_t* __restrict__ xcoef,
-                                                const int32_t* __restrict__ yofs, const uint32_t* __restrict__ ycoef)
+                                                const int32_t* __restrict__ yofs, const uint32_t* __restrict__ ycoef,
+                                                int frame0)
 {
     const int qx = blockIdx.x * 64 + threadIdx.x;
     const int dy = blockIdx.y * 4 + threadIdx.y;
     if(dy >= dh || (qx << 2) >= dw)
         return;
-    const size_t frame = blockIdx.z;
+    const size_t frame = blockIdx.z + frame0;
     const uint8_t* src = pyr + frame * slab + src_off;
     uint8_t* dst = pyr + frame * slab + dst_off;
 
@@ -118,13 +119,14 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
 __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, unsigned slab, int src_off, int sh,
                                                      int spitch, int dst_off, int dw, int dh, int dpitch,
                                                      const uint32_t* __restrict__ qbase, const uint4* __restrict__ qw,
-                                                     const int32_t* __restrict__ yofs, const uint32_t* __restrict__ ycoef)
+                                                     const int32_t* __restrict__ yofs, const uint32_t* __restrict__ ycoef,
+                                                     int frame0)
 {
     const int qx = blockIdx.x * 64 + threadIdx.x;
     const int dy = blockIdx.y * 4 + threadIdx.y;
     if(dy >= dh || (qx << 2) >= dw)
         return;
-    const size_t frame = blockIdx.z;
+    const size_t frame = blockIdx.z + frame0;
     const uint8_t* src = pyr + frame * slab + src_off;
     uint8_t* dst = pyr + frame * slab + dst_off;
 
@@ -171,25 +173,25 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
 }
 
 void launch_resize_quad(uint8_t* d_pyr, const Geometry& g, int level, const uint32_t* d_qbase, const uint4* d_qw,
-                        const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s)
+                        const int32_t* d_yofs, const uint32_t* d_ycoef, int frame0, int n_frames, hipStream_t s)
 {
     const LevelGeom& src = g.lv[level - 1];
     const LevelGeom& dst = g.lv[level];
     const int quads = (dst.w + 3) / 4;
     dim3 grid((quads + 63) / 64, (dst.h + 3) / 4, n_frames);
     hipLaunchKernelGGL(k_resize_quad, grid, dim3(64, 4), 0, s, d_pyr, g.slab, src.offset, src.h, src.pitch, dst.offset,
-                       dst.w, dst.h, dst.pitch, d_qbase, d_qw, d_yofs, d_ycoef);
+                       dst.w, dst.h, dst.pitch, d_qbase, d_qw, d_yofs, d_ycoef, frame0);
 }
 
 void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,
-                   const int32_t* d_yofs, const uint32_t* d_ycoef, int n_frames, hipStream_t s)
+                   const int32_t* d_yofs, const uint32_t* d_ycoef, int frame0, int n_frames, hipStream_t s)
 {
     const LevelGeom& src = g.lv[level - 1];
     const LevelGeom& dst = g.lv[level];
     const int quads = (dst.w + 3) / 4;
     dim3 grid((quads + 63) / 64, (dst.h + 3) / 4, n_frames);
     hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, s, d_pyr, g.slab, src.offset, src.w, src.h, src.pitch, dst.offset,
-                       dst.w, dst.h, dst.pitch, d_xofs, d_xcoef, d_yofs, d_ycoef);
+                       dst.w, dst.h, dst.pitch, d_xofs, d_xcoef, d_yofs, d_ycoef, frame0);
 }
 
 } // namespace mslam

@@ -21,6 +21,7 @@ namespace mslam
 
 constexpr int QT = 512;           // threads per workgroup
 constexpr int kLdsNodes = 2048;   // child counters live in LDS while the list is this short
+constexpr int kLdsKp = 2048;      // levels with at most this many candidates keep ALL working arrays in LDS
 constexpr int kMaxCellsPerLevel = 2048;
 constexpr int kMaxInitNodes = 64;
 constexpr int kMaxPasses = 40;
@@ -81,12 +82,17 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
     __shared__ Scan scan;
     __shared__ uint32_t cell_off[kMaxCellsPerLevel + 1];
     __shared__ uint32_t lds_cc[kLdsNodes * 4];
+    // LDS working set for small levels (the common case): the passes are latency-bound, and an LDS
+    // round trip is ~10x shorter than an L2 one.  Larger levels fall back to the global scratch arrays.
+    __shared__ uint32_t l_cand[kLdsKp], l_kp_node[kLdsKp], l_ncnt_a[kLdsKp], l_ncnt_b[kLdsKp], l_ninfo[kLdsKp],
+        l_nbase[kLdsKp];
+    __shared__ uint2 l_nodes_a[kLdsKp], l_nodes_b[kLdsKp];
     __shared__ uint32_t init_cnt[kMaxInitNodes];
     __shared__ uint32_t init_pos[kMaxInitNodes];
     __shared__ uint32_t sh_n;
 
     const int level = blockIdx.x;
-    const size_t frame = blockIdx.y;
+    const size_t frame = blockIdx.y + g.frame0;
     const LevelGeom& lv = g.lv[level];
     const int tid = threadIdx.x;
     const size_t slot = frame * g.n_levels + level;
@@ -139,6 +145,18 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
             a.sel_cnt[slot] = 0;
         return;
     }
+    uint32_t* g_cand = cand; // the global copy is kept for mslam_hip_debug_read
+    if(N <= (uint32_t)kLdsKp)
+    {
+        cand = l_cand;
+        kp_node = l_kp_node;
+        nodes = l_nodes_a;
+        nodes2 = l_nodes_b;
+        ncnt = l_ncnt_a;
+        ncnt2 = l_ncnt_b;
+        ninfo = l_ninfo;
+        nbase = l_nbase;
+    }
     const uint32_t* ckp = a.cell_kp + (frame * g.n_cells + lv.cell_base) * (size_t)kCellCap;
     for(uint32_t j = tid; j < N; j += QT)
     {
@@ -151,7 +169,10 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
             else
                 hi = mid - 1;
         }
-        cand[j] = ckp[(size_t)lo * kCellCap + (j - cell_off[lo])];
+        const uint32_t v = ckp[(size_t)lo * kCellCap + (j - cell_off[lo])];
+        cand[j] = v;
+        if(cand != g_cand)
+            g_cand[j] = v;
     }
 
     // ---- 1. initial nodes (:1025-1105)
@@ -355,10 +376,12 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
         a.sel_cnt[slot] = n;
 }
 
-void launch_quadtree(const Geometry& g, const QuadArgs& a, int n_frames, hipStream_t s)
+void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_frames, hipStream_t s)
 {
     dim3 grid(g.n_levels, n_frames);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT), 0, s, g, a);
+    Geometry gg = g;
+    gg.frame0 = frame0;
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT), 0, s, gg, a);
 }
 
 } // namespace mslam
