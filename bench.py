@@ -29,6 +29,25 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# integer vector ALU: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (a wave64 VALU op issues over 4 cycles; the
+# 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).  Measured: the matcher loop sustains ~82 % of it.
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "mslam::k_resize_quad", "fast": "mslam::k_fast_cells",
+                "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur", "describe": "mslam::k_describe",
+                "match_knn2": "void mslam::k_match_knn2<8, 1, 8>", "ratio_compact": "mslam::k_ratio_compact"}
+
+
+def pmc_traffic(stage, launches):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced
+    streaming reads — MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known
+    92.16 MB input confirms: it reads 45.0 MB raw).  None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc_fetch_write_per_launch.json")
+    try:
+        d = json.load(open(path))[STAGE_KERNEL[stage]]
+    except (OSError, KeyError, ValueError):
+        return None
+    return int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024)
 
 
 def parse():
@@ -185,11 +204,18 @@ def main():
         launches = 7 if dom == "resize" else 1
         achieved = sb[dom] / (acc[dom] * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, launches),
                     "launches_per_step": launches, "avg_ms": round(acc[dom], 4),
                     "algorithmic_bytes_per_launch": sb[dom] // launches,
                     "stages_ms": {k: round(x, 4) for k, x in acc.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0}}
+        if "match_knn2" in acc:
+            # the matcher is popcount-bound, not HBM-bound: 8 xor + 8 bcnt + 4 top-2 ops per pair
+            pairs = B * (kp_b / B) ** 2
+            tops = pairs * 20 / (acc["match_knn2"] * 1e-3) / 1e12
+            roofline["match_valu"] = {"bound": "int-valu", "pairs_per_launch": int(pairs), "ops_per_pair": 20,
+                                      "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2),
+                                      "unit": "Tlane-op/s", "frac": round(tops / VALU_PEAK_TOPS, 3)}
         w, h, _ = ctx.level_geometry()
         P = sum(x * y for x, y in zip(w, h))
         extract_bytes = 3 * a.width * a.height + 2 * P + 48 * (kp_b / B)
