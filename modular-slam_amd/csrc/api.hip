@@ -391,7 +391,9 @@ static int create_impl(mslam_hip_ctx* c)
                     const uint32_t a0 = coef[x0 + dx] & 0xFFFF, a1 = coef[x0 + dx] >> 16;
                     if(shift < 0 || shift > 10 || a0 > 0xFFF || a1 > 0xFFF)
                         ok = false;
-                    wv[k] = (uint32_t)shift | (a0 << 4) | (a1 << 16);
+                    // bytes shift, shift+1 of the 12-byte window: in dwords (0,1) when shift <= 6, else in (1,2)
+                    const int upper = shift > 6 ? 1 : 0;
+                    wv[k] = (uint32_t)(shift - 4 * upper) | ((uint32_t)upper << 3) | (a0 << 4) | (a1 << 16);
                 }
                 qbase.push_back(base);
                 qw.push_back(make_uint4(wv[0], wv[1], wv[2], wv[3]));

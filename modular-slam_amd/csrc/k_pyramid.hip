@@ -112,10 +112,11 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
 }
 
 // Quad form of the same interpolation: the 4 destination pixels of a lane draw on at most 12
-// consecutive source bytes per row, so the lane loads three ALIGNED dwords per source row and cuts
-// each (S[sx], S[sx+1]) pair out with v_alignbyte/v_perm; the horizontal blend is one v_dot2_u32_u16.
-// Host-built per-quad tables: qbase = byte offset of the aligned window, qw = 4 words
-// (shift | a0 << 4 | a1 << 16), shift = sx - qbase in [0, 10].
+// consecutive source bytes per row, so the lane loads three ALIGNED dwords per source row.  The host
+// table holds, per destination pixel, which dword pair contains its two source bytes and at which byte
+// offset, so ONE v_perm_b32 per row cuts (S[sx], S[sx+1]) out as a u16 pair and the horizontal blend
+// is one v_dot2_u32_u16.  Table word: i0 (3 bits: byte index of S[sx] inside the chosen pair) |
+// upper-pair flag (bit 3) | a0 << 4 | a1 << 16.
 __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, unsigned slab, int src_off, int sh,
                                                      int spitch, int dst_off, int dw, int dh, int dpitch,
                                                      const uint32_t* __restrict__ qbase, const uint4* __restrict__ qw,
@@ -137,39 +138,37 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
     const uint32_t b0 = yc & 0xFFFF, b1 = yc >> 16;
     const uint32_t base = qbase[qx];
     const uint4 w4 = qw[qx];
-    const uint32_t* r0p = reinterpret_cast<const uint32_t*>(src + (size_t)sy0 * spitch + base);
-    const uint32_t* r1p = reinterpret_cast<const uint32_t*>(src + (size_t)sy1 * spitch + base);
+    const uint32_t* r0p = reinterpret_cast<const uint32_t*>(src + sy0 * spitch + base);
+    const uint32_t* r1p = reinterpret_cast<const uint32_t*>(src + sy1 * spitch + base);
     const uint32_t a0 = r0p[0], a1 = r0p[1], a2 = r0p[2];
     const uint32_t c0 = r1p[0], c1 = r1p[1], c2 = r1p[2];
     const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     uint32_t out = 0;
 #pragma unroll
     for(int k = 0; k < 4; ++k)
     {
         const uint32_t w = ws[k];
-        const uint32_t shift = w & 0xF;
+        // selector bytes [i0, zero, i0+1, zero]: the pair lands as two u16 lanes
+        const uint32_t sel = 0x0c010c00u + (w & 7u) * 0x00010001u;
+        const bool upper = (w & 8u) != 0;
+        const uint32_t p0 = __builtin_amdgcn_perm(upper ? a2 : a1, upper ? a1 : a0, sel);
+        const uint32_t p1 = __builtin_amdgcn_perm(upper ? c2 : c1, upper ? c1 : c0, sel);
         const uint32_t coef = ((w >> 4) & 0xFFF) | (w & 0xFFFF0000u); // (a0, a1) as a u16 pair
-        const bool hi = shift >= 4, top = shift >= 8;
-        // 8-byte window holding the pair, then the pair as two u16 lanes
-        const uint32_t lo0 = top ? a2 : (hi ? a1 : a0), hi0 = top ? a2 : (hi ? a2 : a1);
-        const uint32_t lo1 = top ? c2 : (hi ? c1 : c0), hi1 = top ? c2 : (hi ? c2 : c1);
-        const uint32_t p0 = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(hi0, lo0, shift & 3), 0x0c010c00u);
-        const uint32_t p1 = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(hi1, lo1, shift & 3), 0x0c010c00u);
-        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-        u16x2 cv;
+        u16x2 cv, v0, v1;
         cv.x = (unsigned short)(coef & 0xFFFF);
         cv.y = (unsigned short)(coef >> 16);
-        u16x2 v0, v1;
         v0.x = (unsigned short)(p0 & 0xFFFF);
         v0.y = (unsigned short)(p0 >> 16);
         v1.x = (unsigned short)(p1 & 0xFFFF);
         v1.y = (unsigned short)(p1 >> 16);
         const uint32_t r0 = __builtin_amdgcn_udot2(v0, cv, 0u, false);
         const uint32_t r1 = __builtin_amdgcn_udot2(v1, cv, 0u, false);
-        const uint32_t v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        out |= (v & 0xFF) << (8 * k);
+        // both factors are below 2^24 (weights <= 2048, r >> 4 <= 32640): 24-bit multiplies are full rate
+        const uint32_t v = ((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2) >> 2;
+        out |= v << (8 * k); // v <= 255
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + (qx << 2)) = out;
+    *reinterpret_cast<uint32_t*>(dst + dy * dpitch + (qx << 2)) = out;
 }
 
 void launch_resize_quad(uint8_t* d_pyr, const Geometry& g, int level, const uint32_t* d_qbase, const uint4* d_qw,
