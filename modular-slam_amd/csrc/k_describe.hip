@@ -244,14 +244,17 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 const int bx0 = px - kPatchR, sh = bx0 & 3;
                 sh_out = sh;
                 const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * lv.pitch + (bx0 - sh);
+                const uint32_t* bsrc32 = reinterpret_cast<const uint32_t*>(bsrc); // wave-uniform base, 32-bit lane offsets
+                const uint32_t pitch = (uint32_t)lv.pitch;
 #pragma unroll
                 for(int q = 0; q < 7; ++q)
                 {
-                    const int t = lane + 64 * q;
-                    if(t < kPatchRows * kPatchDw)
+                    const uint32_t t = (uint32_t)lane + 64u * q;
+                    if(t < (uint32_t)(kPatchRows * kPatchDw))
                     {
-                        const int r = t / kPatchDw, c = t - r * kPatchDw;
-                        patch[wave][buf][t] = *reinterpret_cast<const uint32_t*>(bsrc + r * lv.pitch + 4 * c);
+                        const uint32_t r = (t * 5958u) >> 16; // t / 11 for t < 429
+                        const uint32_t c = t - r * kPatchDw;
+                        patch[wave][buf][t] = bsrc32[(__umul24(r, pitch) >> 2) + c];
                     }
                 }
             };
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(q.x, ca), __fmul_rn(q.y, sa)));
                     const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(q.z, sa), __fmul_rn(q.w, ca)));
                     const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(q.z, ca), __fmul_rn(q.w, sa)));
-                    const int v0 = bc[r0 * (kPatchDw * 4) + c0];
-                    const int v1 = bc[r1 * (kPatchDw * 4) + c1];
+                    const int v0 = bc[__mul24(r0, kPatchDw * 4) + c0];
+                    const int v1 = bc[__mul24(r1, kPatchDw * 4) + c1];
                     bits[t] = __ballot(v0 < v1);
                 }
                 if(lane < 4)
