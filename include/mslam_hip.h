@@ -174,6 +174,26 @@ int mslam_hip_get_bow_view(mslam_hip_ctx* ctx, mslam_hip_bow_view* view);
 int mslam_hip_bow_cross_score_dev(mslam_hip_ctx* ctx, const uint32_t* d_words, const double* d_values,
                                   const int32_t* d_n, int n_sets, int capacity, double* d_scores);
 
+/* ---- RGB-D back-projection (the step after the matcher) ----------------------------
+ * Replaces pointsFromRgbdKeypoints / reconstructPoint (rgbd_feature_frontend.cpp:101-138) with getDepth /
+ * isDepthValid (types/depth_frame.hpp:20-30).  depth = DepthFrame::data (u16, row-major, width*height),
+ * factor / focal / principal point = CameraParameters (sensors/camera_parameters.hpp:7-12; TUM: 1/5000, 525,
+ * 525, 319.5, 239.5 — rgbd_file_provider.cpp:136-145).  xy = keypoint coordinates as returned by detect.
+ * xyz[3i..3i+2] is the camera-frame point, valid[i] = 1 iff the depth is valid (std::optional engaged). */
+int mslam_hip_backproject(mslam_hip_ctx* ctx, const uint16_t* depth, int width, int height, float factor, double fx,
+                          double fy, double cx, double cy, const float* xy, int n, double* xyz, uint8_t* valid);
+/* Batched device form: every keypoint of the last detect batch against d_depth = n_frames back-to-back
+ * u16 depth frames in HBM.  Results: mslam_hip_points_view. */
+int mslam_hip_backproject_batch_dev(mslam_hip_ctx* ctx, const uint16_t* d_depth, float factor, double fx, double fy,
+                                    double cx, double cy);
+typedef struct
+{
+    int32_t capacity;     /* per-frame stride (in keypoints) */
+    const double* xyz;    /* [max_batch][capacity][3]        */
+    const uint8_t* valid; /* [max_batch][capacity]           */
+} mslam_hip_points_view;
+int mslam_hip_get_points_view(mslam_hip_ctx* ctx, mslam_hip_points_view* view);
+
 /* ---- test / debug access to intermediate stages (host copies; synchronises) -----------------------*/
 enum
 {

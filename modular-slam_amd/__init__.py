@@ -34,7 +34,8 @@ ABI_SYMBOLS = [
     "mslam_hip_bow_load", "mslam_hip_bow_info", "mslam_hip_bow_words", "mslam_hip_bow_transform",
     "mslam_hip_bow_score", "mslam_hip_bow_db_add", "mslam_hip_bow_db_query", "mslam_hip_bow_db_clear",
     "mslam_hip_bow_batch_dev", "mslam_hip_get_bow_view", "mslam_hip_bow_cross_score_dev", "mslam_hip_level_geometry", "mslam_hip_debug_read",
-    "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host",
+    "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host", "mslam_hip_backproject", "mslam_hip_backproject_batch_dev",
+    "mslam_hip_get_points_view",
 ]
 
 
@@ -55,6 +56,10 @@ class BatchView(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("capacity", C.c_int32), ("xy", C.c_void_p), ("desc", C.c_void_p),
                 ("octave", C.c_void_p), ("angle", C.c_void_p), ("response", C.c_void_p), ("count", C.c_void_p),
                 ("match_from", C.c_void_p), ("match_to", C.c_void_p), ("match_count", C.c_void_p)]
+
+
+class PointsView(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("xyz", C.c_void_p), ("valid", C.c_void_p)]
 
 
 class BowView(C.Structure):
@@ -185,6 +190,29 @@ class Context:
         out = [np.empty(n, np.int32) for _ in range(4)]
         self._chk(self.L.mslam_hip_match_knn2(self._h, _p(f), len(f), _p(t), len(t), *[_p(o) for o in out]))
         return tuple(o[:len(t)].copy() for o in out)
+
+    # ---- RGB-D back-projection (rgbd_feature_frontend.cpp:101-138) ------------------------------
+    def backproject(self, depth, xy, factor=1.0 / 5000.0, focal=(525.0, 525.0), principal=(319.5, 239.5)):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        h, w = depth.shape
+        n = len(xy)
+        xyz = np.zeros((max(n, 1), 3), np.float64)
+        valid = np.zeros(max(n, 1), np.uint8)
+        self._chk(self.L.mslam_hip_backproject(self._h, _p(depth), w, h, C.c_float(factor), C.c_double(focal[0]),
+                                               C.c_double(focal[1]), C.c_double(principal[0]), C.c_double(principal[1]),
+                                               _p(xy), n, _p(xyz), _p(valid)))
+        return xyz[:n].copy(), valid[:n].astype(bool)
+
+    def backproject_batch_dev(self, d_depth_ptr, factor=1.0 / 5000.0, focal=(525.0, 525.0), principal=(319.5, 239.5)):
+        self._chk(self.L.mslam_hip_backproject_batch_dev(self._h, C.c_void_p(d_depth_ptr), C.c_float(factor),
+                                                         C.c_double(focal[0]), C.c_double(focal[1]),
+                                                         C.c_double(principal[0]), C.c_double(principal[1])))
+
+    def points_view(self):
+        v = PointsView()
+        self._chk(self.L.mslam_hip_get_points_view(self._h, C.byref(v)))
+        return v
 
     # ---- bag of words --------------------------------------------------------------------------
     def bow_load(self, blob):

@@ -282,7 +282,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_xy, c->d_desc, c->d_octave,
                     c->d_angle,   c->d_response, c->d_count, c->d_idx0, c->d_idx1, c->d_dist0, c->d_dist1, c->d_mfrom,
-                    c->d_mto,     c->d_mcount, c->d_hm_from, c->d_hm_to, c->d_hm_out};
+                    c->d_mto,     c->d_mcount, c->d_hm_from, c->d_hm_to, c->d_hm_out, c->d_xyz, c->d_valid};
     for(void* b : bufs)
         if(b)
             (void)hipFree(b);

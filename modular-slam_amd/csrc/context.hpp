@@ -72,6 +72,10 @@ struct mslam_hip_ctx
     int32_t* d_hm_out = nullptr; // 6 arrays x cap + 1
     int hm_from_cap = 0, hm_to_cap = 0;
 
+    // RGB-D back-projection outputs (allocated on first use)
+    double* d_xyz = nullptr;
+    uint8_t* d_valid = nullptr;
+
     mslam::BowState* bow = nullptr;
 
     bool profiling = false;

@@ -869,6 +869,27 @@ int mso_match(const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int 
     return n;
 }
 
+/* ---- REF/rgbd_feature_frontend.cpp:101-138 -------------------------------------------------- */
+void mso_backproject(const uint16_t* depth, int width, int height, float factor, double fx, double fy, double cx,
+                     double cy, const float* xy, int n, double* xyz, uint8_t* valid)
+{
+    const double inv_fx = 1.0 / fx, inv_fy = 1.0 / fy; /* :126 invFocal = 1.0 / focal.array() */
+    for(int i = 0; i < n; ++i)
+    {
+        const double x = xy[2 * i], y = xy[2 * i + 1];
+        const int ix = (int)x, iy = (int)y; /* coordinates.cast<int>() (:129) */
+        float d = 0.f;
+        if(ix >= 0 && ix < width && iy >= 0 && iy < height)
+            d = (float)depth[(size_t)width * iy + ix] * factor; /* getDepth, depth_frame.hpp:20-25 */
+        const int ok = d > FLT_EPSILON;                         /* isDepthValid, depth_frame.hpp:27-30 */
+        const double z = d;                                     /* :111 */
+        xyz[3 * i] = ok ? (x - cx) * z * inv_fx : 0.0;          /* :112 */
+        xyz[3 * i + 1] = ok ? (y - cy) * z * inv_fy : 0.0;      /* :113 */
+        xyz[3 * i + 2] = ok ? z : 0.0;
+        valid[i] = (uint8_t)ok;
+    }
+}
+
 /* ---- DBoW3 --------------------------------------------------------------------------------- */
 struct mso_voc
 {

@@ -101,6 +101,12 @@ void mso_match_knn2_raw(const uint8_t* from_desc, int n_from, const uint8_t* to_
 int mso_match(const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to, double ratio,
               int32_t* from_idx, int32_t* to_idx);
 
+/* pointsFromRgbdKeypoints + reconstructPoint, rgbd_feature_frontend.cpp:101-138, with getDepth /
+ * isDepthValid, types/depth_frame.hpp:20-30.  xy are the (float) keypoint coordinates, widened to double as
+ * the detector adapter does (distributed_cv_feature.cpp:1207-1208). */
+void mso_backproject(const uint16_t* depth, int width, int height, float factor, double fx, double fy, double cx,
+                     double cy, const float* xy, int n, double* xyz, uint8_t* valid);
+
 /* ---- DBoW3 (rmsalinas/DBow3 master, conan_recipes/dbow3/conanfile.py:9,18) ---------------- */
 typedef struct mso_voc mso_voc;
 enum { MSO_TF_IDF = 0, MSO_TF = 1, MSO_IDF = 2, MSO_BINARY = 3 };

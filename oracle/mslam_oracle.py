@@ -210,6 +210,18 @@ def match(from_desc, to_desc, ratio=0.7):
     return fi[:n].copy(), ti[:n].copy()
 
 
+def backproject(depth, xy, factor=1.0 / 5000.0, focal=(525.0, 525.0), principal=(319.5, 239.5)):
+    depth = np.ascontiguousarray(depth, np.uint16)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    h, w = depth.shape
+    n = len(xy)
+    xyz = np.zeros((max(n, 1), 3), np.float64)
+    valid = np.zeros(max(n, 1), np.uint8)
+    lib().mso_backproject(_p(depth), w, h, C.c_float(factor), C.c_double(focal[0]), C.c_double(focal[1]),
+                          C.c_double(principal[0]), C.c_double(principal[1]), _p(xy), n, _p(xyz), _p(valid))
+    return xyz[:n].copy(), valid[:n].astype(bool)
+
+
 class Vocabulary:
     def __init__(self, blob):
         self._blob = np.frombuffer(bytes(blob), np.uint8) if not isinstance(blob, np.ndarray) else blob

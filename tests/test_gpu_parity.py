@@ -169,3 +169,33 @@ def test_batch_device_path(pkg, orc, synth_frames):
                 assert mc[i] == len(rf)
                 assert np.array_equal(mf[i, :mc[i]], rf) and np.array_equal(mt[i, :mc[i]], rt)
     c.close()
+
+
+def test_backproject_rgbd(pkg, orc, ctx, bundled_frames, bundled_depth):
+    """row f-1: depth lookup + pin-hole back-projection of the detected keypoints (TUM intrinsics)"""
+    det = orc.detect(bundled_frames[0], orc.params())
+    got_xyz, got_ok = ctx.backproject(bundled_depth[0], det["xy"])
+    ref_xyz, ref_ok = orc.backproject(bundled_depth[0], det["xy"])
+    assert np.array_equal(got_ok, ref_ok) and 0.5 < ref_ok.mean() < 1.0   # ~5 % of the depth pixels are 0
+    assert np.array_equal(got_xyz, ref_xyz)                               # f64, bit-exact
+    assert (ref_xyz[ref_ok, 2] > 0).all() and ref_xyz[ref_ok, 2].max() < 6.5
+
+
+def test_backproject_batch_device(pkg, orc, synth_frames):
+    import torch
+    import synth
+    depth = synth.make_depth(3, 640, 480)
+    c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=4096)
+    c.detect_batch_dev(torch.from_numpy(synth_frames[:3]).cuda().data_ptr(), 3)
+    d_depth = torch.from_numpy(np.ascontiguousarray(depth).view(np.int16)).cuda()
+    c.backproject_batch_dev(d_depth.data_ptr())
+    c.sync()
+    v, pv = c.batch_view(), c.points_view()
+    cnt = pkg.read_device(c, v.count, (3,), np.int32)
+    xyz = pkg.read_device(c, pv.xyz, (3, 4096, 3), np.float64)
+    ok = pkg.read_device(c, pv.valid, (3, 4096), np.uint8)
+    for i in range(3):
+        det = orc.detect(synth_frames[i], orc.params())
+        rx, ro = orc.backproject(depth[i], det["xy"])
+        assert np.array_equal(ok[i, :cnt[i]].astype(bool), ro) and np.array_equal(xyz[i, :cnt[i]], rx)
+    c.close()

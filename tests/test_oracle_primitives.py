@@ -265,3 +265,17 @@ def test_bow_against_python(orc):
         assert list(bw) == keys and list(bv) == [acc[k] / norm for k in keys]
     assert orc.bow_score_l1(bw, bv, bw, bv) == pytest.approx(1.0, abs=1e-12)
     assert orc.bow_score_l1(bw[:0], bv[:0], bw, bv) == 0.0
+
+
+def test_backproject_against_numpy(orc, bundled_depth):
+    rng = np.random.default_rng(8)
+    xy = np.stack([rng.uniform(19, 620, 500), rng.uniform(19, 460, 500)], 1).astype(np.float32)
+    xyz, ok = orc.backproject(bundled_depth[0], xy)
+    ix, iy = xy[:, 0].astype(np.float64).astype(int), xy[:, 1].astype(np.float64).astype(int)
+    d = bundled_depth[0][iy, ix].astype(np.float32) * np.float32(1.0 / 5000.0)
+    assert np.array_equal(ok, d > np.finfo(np.float32).eps)
+    z = d.astype(np.float64)
+    ex = (xy[:, 0].astype(np.float64) - 319.5) * z * (1.0 / 525.0)
+    ey = (xy[:, 1].astype(np.float64) - 239.5) * z * (1.0 / 525.0)
+    assert np.array_equal(xyz[ok, 0], ex[ok]) and np.array_equal(xyz[ok, 1], ey[ok]) and np.array_equal(xyz[ok, 2], z[ok])
+    assert (xyz[~ok] == 0).all() and 0.03 < (~ok).mean() < 0.08        # the bundled depth has ~5 % holes
