@@ -278,4 +278,4 @@ def test_backproject_against_numpy(orc, bundled_depth):
     ex = (xy[:, 0].astype(np.float64) - 319.5) * z * (1.0 / 525.0)
     ey = (xy[:, 1].astype(np.float64) - 239.5) * z * (1.0 / 525.0)
     assert np.array_equal(xyz[ok, 0], ex[ok]) and np.array_equal(xyz[ok, 1], ey[ok]) and np.array_equal(xyz[ok, 2], z[ok])
-    assert (xyz[~ok] == 0).all() and 0.03 < (~ok).mean() < 0.08        # the bundled depth has ~5 % holes
+    assert (xyz[~ok] == 0).all() and 0.01 < (~ok).mean() < 0.10        # the bundled depth has ~5 % holes
