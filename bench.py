@@ -53,10 +53,10 @@ def pmc_traffic(stage, launches):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=100, help="frames per step")
-    ap.add_argument("--unique", type=int, default=200, help="distinct synthetic frames kept in HBM (cycled)")
+    ap.add_argument("--batch", type=int, default=250, help="frames per step (4 steps = the 1000-frame stream of cfg2)")
+    ap.add_argument("--unique", type=int, default=500, help="distinct synthetic frames kept in HBM (cycled)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--bow", action="store_true",

@@ -62,6 +62,48 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Scan& s, uint32_
     return base + inc - v;
 }
 
+// the same for two values at once (one pair of barriers)
+__device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, Scan& s, Scan& s2, uint32_t& exa, uint32_t& exb,
+                                                 uint32_t& tota, uint32_t& totb)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b;
+#pragma unroll
+    for(int o = 1; o < 64; o <<= 1)
+    {
+        const uint32_t ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+        if(lane >= o)
+        {
+            ia += ta;
+            ib += tb;
+        }
+    }
+    if(lane == 63)
+    {
+        s.wsum[wave] = ia;
+        s2.wsum[wave] = ib;
+    }
+    __syncthreads();
+    uint32_t ba = 0, bb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for(int w = 0; w < QT / 64; ++w)
+    {
+        const uint32_t x = s.wsum[w], y = s2.wsum[w];
+        if(w < wave)
+        {
+            ba += x;
+            bb += y;
+        }
+        ta += x;
+        tb += y;
+    }
+    __syncthreads();
+    tota = ta;
+    totb = tb;
+    exa = ba + ia - a;
+    exb = bb + ib - b;
+}
+
 __device__ __forceinline__ uint32_t ld_atomic(const uint32_t* p)
 {
     // values produced by atomics must not be served from a stale L1 line
@@ -77,9 +119,236 @@ __device__ __forceinline__ uint2 pack_node(int bx, int by, int ex, int ey)
     return make_uint2((uint32_t)bx | ((uint32_t)by << 16), (uint32_t)ex | ((uint32_t)ey << 16));
 }
 
+// Everything after the candidate count is known.  Instantiated twice and force-inlined so that, in the
+// kLds instance, every working array is a known LDS object (ds_* instructions instead of flat_*).
+template <bool kLds>
+__device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, const LevelGeom& lv, size_t frame,
+                                         size_t slot, int tid, uint32_t N, int n_cells, const uint32_t* cell_off,
+                                         uint32_t* cand, uint32_t* g_cand, uint32_t* kp_node, uint2* nodes,
+                                         uint2* nodes2, uint32_t* ncnt, uint32_t* ncnt2, uint32_t* ninfo,
+                                         uint32_t* nbase, uint32_t* lds_cc, uint32_t* g_cc, uint32_t* sel, Scan& scan,
+                                         Scan& scan2, uint32_t* init_cnt, uint32_t* init_pos, uint32_t& sh_n)
+{
+    const uint32_t* ckp = a.cell_kp + (frame * g.n_cells + lv.cell_base) * (size_t)kCellCap;
+    for(uint32_t j = tid; j < N; j += QT)
+    {
+        int lo = 0, hi = n_cells - 1; // last cell with cell_off <= j
+        while(lo < hi)
+        {
+            const int mid = (lo + hi + 1) >> 1;
+            if(cell_off[mid] <= j)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const uint32_t v = ckp[(size_t)lo * kCellCap + (j - cell_off[lo])];
+        cand[j] = v;
+        if(kLds)
+            g_cand[j] = v; // the global copy is kept for mslam_hip_debug_read
+    }
+
+    // ---- 1. initial nodes (:1025-1105)
+    const int n_init = lv.nxg * lv.nyg;
+    if(tid < kMaxInitNodes)
+        init_cnt[tid] = 0;
+    __syncthreads();
+    for(uint32_t k = tid; k < N; k += QT)
+    {
+        const uint32_t p = cand[k];
+        const unsigned ix = (unsigned)((double)(float)kp_x(p) / lv.delta_x);
+        const unsigned iy = (unsigned)((double)(float)kp_y(p) / lv.delta_y);
+        const unsigned idx = ix + iy * (unsigned)lv.nxg;
+        if(idx < (unsigned)n_init)
+        {
+            atomicAdd(&init_cnt[idx], 1u);
+            kp_node[k] = idx;
+        }
+        else
+            kp_node[k] = kNoNode;
+    }
+    __syncthreads();
+    if(tid == 0)
+    {
+        uint32_t n0 = 0;
+        for(int i = 0; i < n_init; ++i)
+        {
+            init_pos[i] = n0;
+            if(init_cnt[i] != 0)
+            {
+                const int ix = i % lv.nxg, iy = i / lv.nxg;
+                nodes[n0] = pack_node((int)(lv.delta_x * ix), (int)(lv.delta_y * iy), (int)(lv.delta_x * (ix + 1)),
+                                      (int)(lv.delta_y * (iy + 1)));
+                ncnt[n0] = init_cnt[i];
+                ++n0;
+            }
+        }
+        sh_n = n0;
+    }
+    __syncthreads();
+    for(uint32_t k = tid; k < N; k += QT)
+    {
+        const uint32_t idx = kp_node[k];
+        if(idx != kNoNode)
+            kp_node[k] = init_pos[idx];
+    }
+    uint32_t n = sh_n;
+    __syncthreads();
+
+    // ---- 2. subdivision passes (:992-1020)
+    const float sf = lv.scale;
+    const float min_size_f = (float)a.min_size;
+    bool converged = false;
+    for(int pass = 0; pass < kMaxPasses && n > 0; ++pass)
+    {
+        uint32_t* cc = (kLds || n <= (uint32_t)kLdsNodes) ? lds_cc : g_cc;
+        // a. which nodes divide (:1002)
+        for(uint32_t pos = tid; pos < n; pos += QT)
+        {
+            int bx, by, ex, ey;
+            unpack_node(nodes[pos], bx, by, ex, ey);
+            const unsigned area = (unsigned)((ex - bx) * (ey - by));
+            const bool keep = ncnt[pos] == 1u || __fmul_rn(__fmul_rn((float)area, sf), sf) <= min_size_f;
+            ninfo[pos] = keep ? 0u : 1u;
+            if(!keep)
+            {
+                cc[4 * pos + 0] = 0;
+                cc[4 * pos + 1] = 0;
+                cc[4 * pos + 2] = 0;
+                cc[4 * pos + 3] = 0;
+            }
+        }
+        __syncthreads();
+        // b. count keypoints per child (:340-352)
+        for(uint32_t k = tid; k < N; k += QT)
+        {
+            const uint32_t pos = kp_node[k];
+            if(pos == kNoNode || !(ninfo[pos] & 1u))
+                continue;
+            int bx, by, ex, ey;
+            unpack_node(nodes[pos], bx, by, ex, ey);
+            const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1); // cvCeil(d/2.0)
+            const uint32_t p = cand[k];
+            const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
+            atomicAdd(&cc[4 * pos + c], 1u);
+        }
+        __syncthreads();
+        // c. list positions after this pass
+        uint32_t D = 0, U = 0;
+        for(uint32_t base = 0; base < n; base += QT)
+        {
+            const uint32_t pos = base + tid;
+            uint32_t nchild = 0, und = 0, mask = 0, div = 0;
+            if(pos < n)
+            {
+                div = ninfo[pos] & 1u;
+                if(div)
+                {
+                    mask = (ld_atomic(&cc[4 * pos + 0]) ? 1u : 0u) | (ld_atomic(&cc[4 * pos + 1]) ? 2u : 0u) |
+                           (ld_atomic(&cc[4 * pos + 2]) ? 4u : 0u) | (ld_atomic(&cc[4 * pos + 3]) ? 8u : 0u);
+                    nchild = (uint32_t)__popc(mask);
+                }
+                else
+                    und = 1;
+            }
+            uint32_t totD, totU, exD, exU;
+            block_excl_scan2(nchild, und, scan, scan2, exD, exU, totD, totU);
+            if(pos < n)
+            {
+                ninfo[pos] = div | (mask << 1);
+                nbase[pos] = div ? D + exD : U + exU;
+            }
+            D += totD;
+            U += totU;
+        }
+        const uint32_t T = D;
+        __syncthreads();
+        // d. materialise the new list; e. re-point the keypoints.  Both only read what step c wrote
+        //    (nbase = scan prefix, ninfo = divide flag + child mask) and T, so they share one phase.
+        for(uint32_t pos = tid; pos < n; pos += QT)
+        {
+            const uint32_t info = ninfo[pos];
+            if(info & 1u)
+            {
+                int bx, by, ex, ey;
+                unpack_node(nodes[pos], bx, by, ex, ey);
+                const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
+                const uint32_t first = T - 1 - nbase[pos];
+                const uint32_t mask = info >> 1;
+                uint32_t r = 0;
+                if(mask & 1u) { nodes2[first - r] = pack_node(bx, by, cx, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 0]); ++r; }
+                if(mask & 2u) { nodes2[first - r] = pack_node(cx, by, ex, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 1]); ++r; }
+                if(mask & 4u) { nodes2[first - r] = pack_node(bx, cy, cx, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 2]); ++r; }
+                if(mask & 8u) { nodes2[first - r] = pack_node(cx, cy, ex, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 3]); ++r; }
+            }
+            else
+            {
+                const uint32_t np = T + nbase[pos];
+                nodes2[np] = nodes[pos];
+                ncnt2[np] = ncnt[pos];
+            }
+        }
+        for(uint32_t k = tid; k < N; k += QT)
+        {
+            const uint32_t pos = kp_node[k];
+            if(pos == kNoNode)
+                continue;
+            const uint32_t info = ninfo[pos];
+            uint32_t np;
+            if(info & 1u)
+            {
+                int bx, by, ex, ey;
+                unpack_node(nodes[pos], bx, by, ex, ey);
+                const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
+                const uint32_t p = cand[k];
+                const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
+                np = T - 1 - nbase[pos] - (uint32_t)__popc((info >> 1) & ((1u << c) - 1u));
+            }
+            else
+                np = T + nbase[pos];
+            kp_node[k] = np;
+        }
+        __syncthreads();
+        {
+            uint2* t = nodes; nodes = nodes2; nodes2 = t;
+            uint32_t* u = ncnt; ncnt = ncnt2; ncnt2 = u;
+        }
+        const uint32_t n2 = T + U;
+        const bool same = n2 == n; // :1016-1019 — the pass's effects stay even when it is the last
+        n = n2;
+        if(same)
+        {
+            converged = true;
+            break;
+        }
+    }
+    if(!converged && n > 0 && tid == 0)
+        atomicOr(a.flags, kFlagQuadNoConverge);
+
+    // ---- 3. winner per node, emitted in list order (:1128-1155)
+    uint32_t* best = nbase;
+    for(uint32_t pos = tid; pos < n; pos += QT)
+        best[pos] = 0;
+    __syncthreads();
+    for(uint32_t k = tid; k < N; k += QT)
+    {
+        const uint32_t pos = kp_node[k];
+        if(pos == kNoNode)
+            continue;
+        atomicMax(&best[pos], ((uint32_t)kp_score(cand[k]) << 24) | (0xFFFFFFu - k));
+    }
+    __syncthreads();
+    for(uint32_t pos = tid; pos < n; pos += QT)
+    {
+        const uint32_t k = 0xFFFFFFu - (ld_atomic(&best[pos]) & 0xFFFFFFu);
+        sel[pos] = cand[k];
+    }
+    if(tid == 0)
+        a.sel_cnt[slot] = n;
+}
+
 __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
 {
-    __shared__ Scan scan;
+    __shared__ Scan scan, scan2;
     __shared__ uint32_t cell_off[kMaxCellsPerLevel + 1];
     __shared__ uint32_t lds_cc[kLdsNodes * 4];
     // LDS working set for small levels (the common case): the passes are latency-bound, and an LDS
@@ -145,235 +414,12 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
             a.sel_cnt[slot] = 0;
         return;
     }
-    uint32_t* g_cand = cand; // the global copy is kept for mslam_hip_debug_read
     if(N <= (uint32_t)kLdsKp)
-    {
-        cand = l_cand;
-        kp_node = l_kp_node;
-        nodes = l_nodes_a;
-        nodes2 = l_nodes_b;
-        ncnt = l_ncnt_a;
-        ncnt2 = l_ncnt_b;
-        ninfo = l_ninfo;
-        nbase = l_nbase;
-    }
-    const uint32_t* ckp = a.cell_kp + (frame * g.n_cells + lv.cell_base) * (size_t)kCellCap;
-    for(uint32_t j = tid; j < N; j += QT)
-    {
-        int lo = 0, hi = n_cells - 1; // last cell with cell_off <= j
-        while(lo < hi)
-        {
-            const int mid = (lo + hi + 1) >> 1;
-            if(cell_off[mid] <= j)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        const uint32_t v = ckp[(size_t)lo * kCellCap + (j - cell_off[lo])];
-        cand[j] = v;
-        if(cand != g_cand)
-            g_cand[j] = v;
-    }
-
-    // ---- 1. initial nodes (:1025-1105)
-    const int n_init = lv.nxg * lv.nyg;
-    if(tid < kMaxInitNodes)
-        init_cnt[tid] = 0;
-    __syncthreads();
-    for(uint32_t k = tid; k < N; k += QT)
-    {
-        const uint32_t p = cand[k];
-        const unsigned ix = (unsigned)((double)(float)kp_x(p) / lv.delta_x);
-        const unsigned iy = (unsigned)((double)(float)kp_y(p) / lv.delta_y);
-        const unsigned idx = ix + iy * (unsigned)lv.nxg;
-        if(idx < (unsigned)n_init)
-        {
-            atomicAdd(&init_cnt[idx], 1u);
-            kp_node[k] = idx;
-        }
-        else
-            kp_node[k] = kNoNode;
-    }
-    __syncthreads();
-    if(tid == 0)
-    {
-        uint32_t n0 = 0;
-        for(int i = 0; i < n_init; ++i)
-        {
-            init_pos[i] = n0;
-            if(init_cnt[i] != 0)
-            {
-                const int ix = i % lv.nxg, iy = i / lv.nxg;
-                nodes[n0] = pack_node((int)(lv.delta_x * ix), (int)(lv.delta_y * iy), (int)(lv.delta_x * (ix + 1)),
-                                      (int)(lv.delta_y * (iy + 1)));
-                ncnt[n0] = init_cnt[i];
-                ++n0;
-            }
-        }
-        sh_n = n0;
-    }
-    __syncthreads();
-    for(uint32_t k = tid; k < N; k += QT)
-    {
-        const uint32_t idx = kp_node[k];
-        if(idx != kNoNode)
-            kp_node[k] = init_pos[idx];
-    }
-    uint32_t n = sh_n;
-    __syncthreads();
-
-    // ---- 2. subdivision passes (:992-1020)
-    const float sf = lv.scale;
-    const float min_size_f = (float)a.min_size;
-    bool converged = false;
-    for(int pass = 0; pass < kMaxPasses && n > 0; ++pass)
-    {
-        uint32_t* cc = n <= (uint32_t)kLdsNodes ? lds_cc : g_cc;
-        // a. which nodes divide (:1002)
-        for(uint32_t pos = tid; pos < n; pos += QT)
-        {
-            int bx, by, ex, ey;
-            unpack_node(nodes[pos], bx, by, ex, ey);
-            const unsigned area = (unsigned)((ex - bx) * (ey - by));
-            const bool keep = ncnt[pos] == 1u || __fmul_rn(__fmul_rn((float)area, sf), sf) <= min_size_f;
-            ninfo[pos] = keep ? 0u : 1u;
-            if(!keep)
-            {
-                cc[4 * pos + 0] = 0;
-                cc[4 * pos + 1] = 0;
-                cc[4 * pos + 2] = 0;
-                cc[4 * pos + 3] = 0;
-            }
-        }
-        __syncthreads();
-        // b. count keypoints per child (:340-352)
-        for(uint32_t k = tid; k < N; k += QT)
-        {
-            const uint32_t pos = kp_node[k];
-            if(pos == kNoNode || !(ninfo[pos] & 1u))
-                continue;
-            int bx, by, ex, ey;
-            unpack_node(nodes[pos], bx, by, ex, ey);
-            const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1); // cvCeil(d/2.0)
-            const uint32_t p = cand[k];
-            const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
-            atomicAdd(&cc[4 * pos + c], 1u);
-        }
-        __syncthreads();
-        // c. list positions after this pass
-        uint32_t D = 0, U = 0;
-        for(uint32_t base = 0; base < n; base += QT)
-        {
-            const uint32_t pos = base + tid;
-            uint32_t nchild = 0, und = 0, mask = 0, div = 0;
-            if(pos < n)
-            {
-                div = ninfo[pos] & 1u;
-                if(div)
-                {
-                    mask = (ld_atomic(&cc[4 * pos + 0]) ? 1u : 0u) | (ld_atomic(&cc[4 * pos + 1]) ? 2u : 0u) |
-                           (ld_atomic(&cc[4 * pos + 2]) ? 4u : 0u) | (ld_atomic(&cc[4 * pos + 3]) ? 8u : 0u);
-                    nchild = (uint32_t)__popc(mask);
-                }
-                else
-                    und = 1;
-            }
-            uint32_t totD, totU;
-            const uint32_t exD = block_excl_scan(nchild, scan, totD);
-            const uint32_t exU = block_excl_scan(und, scan, totU);
-            if(pos < n)
-            {
-                ninfo[pos] = div | (mask << 1);
-                nbase[pos] = div ? D + exD : U + exU;
-            }
-            D += totD;
-            U += totU;
-        }
-        const uint32_t T = D;
-        __syncthreads();
-        // d. materialise the new list
-        for(uint32_t pos = tid; pos < n; pos += QT)
-        {
-            const uint32_t info = ninfo[pos];
-            if(info & 1u)
-            {
-                int bx, by, ex, ey;
-                unpack_node(nodes[pos], bx, by, ex, ey);
-                const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
-                const uint32_t first = T - 1 - nbase[pos];
-                const uint32_t mask = info >> 1;
-                uint32_t r = 0;
-                if(mask & 1u) { nodes2[first - r] = pack_node(bx, by, cx, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 0]); ++r; }
-                if(mask & 2u) { nodes2[first - r] = pack_node(cx, by, ex, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 1]); ++r; }
-                if(mask & 4u) { nodes2[first - r] = pack_node(bx, cy, cx, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 2]); ++r; }
-                if(mask & 8u) { nodes2[first - r] = pack_node(cx, cy, ex, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 3]); ++r; }
-                nbase[pos] = first;
-            }
-            else
-            {
-                const uint32_t np = T + nbase[pos];
-                nodes2[np] = nodes[pos];
-                ncnt2[np] = ncnt[pos];
-                nbase[pos] = np;
-            }
-        }
-        __syncthreads();
-        // e. re-point the keypoints
-        for(uint32_t k = tid; k < N; k += QT)
-        {
-            const uint32_t pos = kp_node[k];
-            if(pos == kNoNode)
-                continue;
-            const uint32_t info = ninfo[pos];
-            uint32_t np = nbase[pos];
-            if(info & 1u)
-            {
-                int bx, by, ex, ey;
-                unpack_node(nodes[pos], bx, by, ex, ey);
-                const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
-                const uint32_t p = cand[k];
-                const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
-                np -= (uint32_t)__popc((info >> 1) & ((1u << c) - 1u));
-            }
-            kp_node[k] = np;
-        }
-        __syncthreads();
-        {
-            uint2* t = nodes; nodes = nodes2; nodes2 = t;
-            uint32_t* u = ncnt; ncnt = ncnt2; ncnt2 = u;
-        }
-        const uint32_t n2 = T + U;
-        const bool same = n2 == n; // :1016-1019 — the pass's effects stay even when it is the last
-        n = n2;
-        if(same)
-        {
-            converged = true;
-            break;
-        }
-    }
-    if(!converged && n > 0 && tid == 0)
-        atomicOr(a.flags, kFlagQuadNoConverge);
-
-    // ---- 3. winner per node, emitted in list order (:1128-1155)
-    uint32_t* best = nbase;
-    for(uint32_t pos = tid; pos < n; pos += QT)
-        best[pos] = 0;
-    __syncthreads();
-    for(uint32_t k = tid; k < N; k += QT)
-    {
-        const uint32_t pos = kp_node[k];
-        if(pos == kNoNode)
-            continue;
-        atomicMax(&best[pos], ((uint32_t)kp_score(cand[k]) << 24) | (0xFFFFFFu - k));
-    }
-    __syncthreads();
-    for(uint32_t pos = tid; pos < n; pos += QT)
-    {
-        const uint32_t k = 0xFFFFFFu - (ld_atomic(&best[pos]) & 0xFFFFFFu);
-        sel[pos] = cand[k];
-    }
-    if(tid == 0)
-        a.sel_cnt[slot] = n;
+        quad_run<true>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, l_cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
+                       l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, lds_cc, g_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
+    else
+        quad_run<false>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, kp_node, nodes, nodes2, ncnt, ncnt2,
+                        ninfo, nbase, lds_cc, g_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
 }
 
 void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_frames, hipStream_t s)
