@@ -42,7 +42,7 @@ def pmc_traffic(stage, launches):
     collected in separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced
     streaming reads — MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known
     92.16 MB input confirms: it reads 45.0 MB raw).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_b_pmc_fetch_write_per_launch.json")
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write_per_launch.json")
     try:
         d = json.load(open(path))[STAGE_KERNEL[stage]]
     except (OSError, KeyError, ValueError):
