@@ -37,17 +37,19 @@ STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "mslam::k_resize_quad", "fas
                 "match_knn2": "void mslam::k_match_knn2<8, 1, 8>", "ratio_compact": "mslam::k_ratio_compact"}
 
 
-def pmc_traffic(stage, launches):
+def pmc_traffic(stage, launches, frames_per_launch):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced
     streaming reads — MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known
     92.16 MB input confirms: it reads 45.0 MB raw).  None when no profile is committed."""
     path = os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write_per_launch.json")
     try:
-        d = json.load(open(path))[STAGE_KERNEL[stage]]
+        j = json.load(open(path))
+        d = j[STAGE_KERNEL[stage]]
+        scale = frames_per_launch / float(j["_meta"]["frames_per_launch"])  # traffic is linear in the batch size
     except (OSError, KeyError, ValueError):
         return None
-    return int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024)
+    return int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024 * scale)
 
 
 def parse():
@@ -63,6 +65,7 @@ def parse():
                     help="cfg3/cfg4: also DBoW3 loop scoring every frame (synthetic k=10 vocabulary) and, with "
                          "N>1, the RCCL all-gather of BoW vectors + cross-stream scoring")
     ap.add_argument("--voc-levels", type=int, default=6, help="vocabulary depth L (k=10): 6 -> 1e6 words")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU run) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames of the stream timed on the CPU oracle")
     return ap.parse_args()
@@ -122,9 +125,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    # rehearsal aid: MSLAM_BENCH_DEVICE pins every rank to one GPU (only meaningful with --dist-backend gloo)
+    dev = int(os.environ.get("MSLAM_BENCH_DEVICE", local))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(a.dist_backend)
+    torch.cuda.set_device(dev)
+    red_dev = "cuda" if a.dist_backend == "nccl" else "cpu"
 
     import synth
     import __graft_entry__ as graft
@@ -137,7 +146,7 @@ def main():
     frame_bytes = a.width * a.height * 3
 
     ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, max_keypoints=4096, max_candidates=16384,
-                      device=local)
+                      device=dev)
     n_batches = n_unique // B
     cross = None
     if a.bow:
@@ -180,8 +189,8 @@ def main():
         cand_per_batch.append(sum(len(ctx.debug_keypoints(pkg.DBG_CANDIDATES, 0, l)) for l in range(8)) * B)
     n_kp = sum(counts_per_batch[(a.warmup + i) % n_batches] for i in range(a.steps))
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    kp_sum = torch.tensor([float(n_kp)], dtype=torch.float64, device="cuda")
+    t_max = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    kp_sum = torch.tensor([float(n_kp)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(kp_sum, op=dist.ReduceOp.SUM)
@@ -204,7 +213,7 @@ def main():
         launches = 7 if dom == "resize" else 1
         achieved = sb[dom] / (acc[dom] * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, launches),
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, launches, B),
                     "launches_per_step": launches, "avg_ms": round(acc[dom], 4),
                     "algorithmic_bytes_per_launch": sb[dom] // launches,
                     "stages_ms": {k: round(x, 4) for k, x in acc.items()},

@@ -32,6 +32,16 @@ static thread_local std::string g_create_error;
         }                                                                                                              \
     } while(0)
 
+// HIP's current device is per host thread: make the context's device current on every entry so that
+// allocations and launches land on it no matter what the caller did in between.
+#define ENTER(c)                                                                                                       \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if(!(c))                                                                                                       \
+            return MSLAM_HIP_E_INVALID;                                                                                \
+        HIPCHK(c, hipSetDevice((c)->p.device));                                                                        \
+    } while(0)
+
 static int fail(mslam_hip_ctx* c, int code, const std::string& msg)
 {
     c->err = msg;
@@ -517,15 +527,13 @@ static int check_flags(mslam_hip_ctx* c)
 
 int mslam_hip_sync(mslam_hip_ctx* c)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     return check_flags(c);
 }
 
 int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     if(!d_bgr || n_frames < 1 || n_frames > c->p.max_batch)
         return fail(c, MSLAM_HIP_E_INVALID, "detect_batch_dev: n_frames outside [1, max_batch]");
     const Geometry& g = c->geom;
@@ -636,8 +644,7 @@ int mslam_hip_get_batch_view(mslam_hip_ctx* c, mslam_hip_batch_view* v)
 int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height, int max_out, float* xy,
                      uint8_t* desc, int32_t* octave, float* angle, float* response, int* n_out)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     if(n_out)
         *n_out = 0;
     if(!bgr || !n_out || max_out < 0 || (max_out > 0 && (!xy || !desc)))
@@ -696,8 +703,7 @@ static int upload_ratio_table(mslam_hip_ctx* c, double ratio)
 
 int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     if(c->n_last < 1)
         return fail(c, MSLAM_HIP_E_INVALID, "match_batch_dev: no detect batch to match");
     int rc = upload_ratio_table(c, ratio);
@@ -795,8 +801,7 @@ static void host_match_args(mslam_hip_ctx* c, int n_from, int n_to, MatchArgs& m
 int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,
                          int32_t* idx0, int32_t* idx1, int32_t* dist0, int32_t* dist1)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     if(n_from < 0 || n_to < 0 || (n_from > 0 && !from_desc) || (n_to > 0 && (!to_desc || !idx0 || !idx1 || !dist0 || !dist1)))
         return fail(c, MSLAM_HIP_E_INVALID, "match_knn2: bad argument");
     if(n_from > 65535)
@@ -821,8 +826,7 @@ int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from,
 int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,
                     double ratio, int32_t* from_idx, int32_t* to_idx, int* n_out)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     if(n_out)
         *n_out = 0;
     if(!n_out || n_from < 0 || n_to < 0 || (n_from > 0 && !from_desc) || (n_to > 0 && (!to_desc || !from_idx || !to_idx)))
@@ -886,8 +890,7 @@ int mslam_hip_level_geometry(mslam_hip_ctx* c, int* widths, int* heights, float*
 int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void* dst, size_t dst_bytes,
                          size_t* n_items)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     if(frame < 0 || frame >= c->p.max_batch || level < 0 || level >= c->geom.n_levels || !dst || !n_items)
         return fail(c, MSLAM_HIP_E_INVALID, "debug_read: bad argument");
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -929,8 +932,7 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
 
 int mslam_hip_copy_to_host(mslam_hip_ctx* c, void* dst_host, const void* src_dev, size_t bytes)
 {
-    if(!c)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
     if(!dst_host || !src_dev)
         return fail(c, MSLAM_HIP_E_INVALID, "copy_to_host: null pointer");
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -949,8 +951,9 @@ int mslam_hip_set_profiling(mslam_hip_ctx* c, int enable)
 
 int mslam_hip_get_stage_times(mslam_hip_ctx* c, const char** names, float* ms, int cap, int* n)
 {
-    if(!c || !n)
-        return MSLAM_HIP_E_INVALID;
+    ENTER(c);
+    if(!n)
+        return fail(c, MSLAM_HIP_E_INVALID, "get_stage_times: null output");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int k = 0;
     for(size_t i = 0; i < c->timers_used && k < cap; ++i, ++k)

@@ -771,6 +771,7 @@ static int need_voc(mslam_hip_ctx* c)
         c->err = "no vocabulary loaded (call mslam_hip_bow_load first)";
         return MSLAM_HIP_E_NO_VOCABULARY;
     }
+    BHIPCHK(c, hipSetDevice(c->p.device));
     return MSLAM_HIP_OK;
 }
 
@@ -793,6 +794,7 @@ int mslam_hip_bow_load(mslam_hip_ctx* c, const void* blob, size_t size)
         return MSLAM_HIP_E_INVALID;
     if(!blob)
         return bfail(c, MSLAM_HIP_E_INVALID, "bow_load: null blob");
+    BHIPCHK(c, hipSetDevice(c->p.device));
     if(hipStreamSynchronize(c->stream) != hipSuccess)
         return bfail(c, MSLAM_HIP_E_RUNTIME, "bow_load: stream sync failed");
     return bow_load_impl(c, blob, size);

@@ -87,6 +87,7 @@ int mslam_hip_backproject_batch_dev(mslam_hip_ctx* c, const uint16_t* d_depth, f
         return pfail(c, "backproject_batch_dev: bad argument");
     if(c->n_last < 1)
         return pfail(c, "backproject_batch_dev: no detect batch");
+    PHIPCHK(c, hipSetDevice(c->p.device));
     int rc = ensure_points(c);
     if(rc)
         return rc;
@@ -123,6 +124,7 @@ int mslam_hip_backproject(mslam_hip_ctx* c, const uint16_t* depth, int width, in
         return pfail(c, "backproject: bad argument");
     if(n == 0)
         return MSLAM_HIP_OK;
+    PHIPCHK(c, hipSetDevice(c->p.device));
     uint16_t* d_depth = nullptr;
     float* d_xy = nullptr;
     double* d_xyz = nullptr;
