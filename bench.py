@@ -179,12 +179,12 @@ def main():
     dt = time.perf_counter() - t0
 
     # units processed: keypoints extracted (and matched against the previous frame) in the timed steps
-    v = ctx.batch_view()
     counts_per_batch = []
     cand_per_batch = []
     for b in range(n_batches):  # untimed: count keypoints of each distinct batch once
         ctx.detect_batch_dev(d_frames.data_ptr() + b * B * frame_bytes, B)
         ctx.sync()
+        v = ctx.batch_view()  # the output set alternates between batches: fetch the view after every detect
         counts_per_batch.append(int(pkg.read_device(ctx, v.count, (B,), np.int32).sum()))
         cand_per_batch.append(sum(len(ctx.debug_keypoints(pkg.DBG_CANDIDATES, 0, l)) for l in range(8)) * B)
     n_kp = sum(counts_per_batch[(a.warmup + i) % n_batches] for i in range(a.steps))

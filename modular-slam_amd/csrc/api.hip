@@ -290,12 +290,26 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
     void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_rs_qbase, c->d_rs_qw, c->d_ratio_thr, c->d_orient_w, c->d_stage,  c->d_pyr,
                     c->d_blur,    c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
-                    c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_xy, c->d_desc, c->d_octave,
-                    c->d_angle,   c->d_response, c->d_count, c->d_idx0, c->d_idx1, c->d_dist0, c->d_dist1, c->d_mfrom,
-                    c->d_mto,     c->d_mcount, c->d_hm_from, c->d_hm_to, c->d_hm_out, c->d_xyz, c->d_valid};
+                    c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_to, c->d_hm_out,
+                    c->d_xyz, c->d_valid};
     for(void* b : bufs)
         if(b)
             (void)hipFree(b);
+    if(c->stream_m)
+        (void)hipStreamSynchronize(c->stream_m);
+    for(auto& o : c->out)
+    {
+        void* ob[] = {o.xy, o.desc, o.octave, o.angle, o.response, o.count, o.idx0, o.idx1, o.dist0, o.dist1, o.mfrom, o.mto, o.mcount};
+        for(void* b : ob)
+            if(b)
+                (void)hipFree(b);
+        if(o.ev_detect)
+            (void)hipEventDestroy(o.ev_detect);
+        if(o.ev_match)
+            (void)hipEventDestroy(o.ev_match);
+    }
+    if(c->stream_m)
+        (void)hipStreamDestroy(c->stream_m);
     for(auto& t : c->timers)
     {
         (void)hipEventDestroy(t.start);
@@ -318,6 +332,15 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
     if(c->own_stream && c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+static void select_set(mslam_hip_ctx* c, int k)
+{
+    const mslam_out_set& o = c->out[k];
+    c->cur = k;
+    c->d_xy = o.xy, c->d_desc = o.desc, c->d_octave = o.octave, c->d_angle = o.angle, c->d_response = o.response;
+    c->d_count = o.count, c->d_idx0 = o.idx0, c->d_idx1 = o.idx1, c->d_dist0 = o.dist0, c->d_dist1 = o.dist1;
+    c->d_mfrom = o.mfrom, c->d_mto = o.mto, c->d_mcount = o.mcount;
 }
 
 static int create_impl(mslam_hip_ctx* c)
@@ -465,21 +488,32 @@ static int create_impl(mslam_hip_ctx* c)
     q.cand_cap = p.max_candidates;
     q.min_size = p.min_node_area;
 
-    HIPCHK(c, dmalloc(c->d_xy, (B + 1) * K * 2));
-    HIPCHK(c, dmalloc(c->d_desc, (B + 1) * K * 32));
-    HIPCHK(c, dmalloc(c->d_octave, (B + 1) * K));
-    HIPCHK(c, dmalloc(c->d_angle, (B + 1) * K));
-    HIPCHK(c, dmalloc(c->d_response, (B + 1) * K));
-    HIPCHK(c, dmalloc(c->d_count, B + 1));
-    HIPCHK(c, hipMemset(c->d_count, 0, (B + 1) * 4));
-    HIPCHK(c, dmalloc(c->d_idx0, B * K));
-    HIPCHK(c, dmalloc(c->d_idx1, B * K));
-    HIPCHK(c, dmalloc(c->d_dist0, B * K));
-    HIPCHK(c, dmalloc(c->d_dist1, B * K));
-    HIPCHK(c, dmalloc(c->d_mfrom, B * K));
-    HIPCHK(c, dmalloc(c->d_mto, B * K));
-    HIPCHK(c, dmalloc(c->d_mcount, B));
-    HIPCHK(c, hipMemset(c->d_mcount, 0, B * 4));
+    for(auto& o : c->out)
+    {
+        HIPCHK(c, dmalloc(o.xy, (B + 1) * K * 2));
+        HIPCHK(c, dmalloc(o.desc, (B + 1) * K * 32));
+        HIPCHK(c, dmalloc(o.octave, (B + 1) * K));
+        HIPCHK(c, dmalloc(o.angle, (B + 1) * K));
+        HIPCHK(c, dmalloc(o.response, (B + 1) * K));
+        HIPCHK(c, dmalloc(o.count, B + 1));
+        HIPCHK(c, hipMemset(o.count, 0, (B + 1) * 4));
+        HIPCHK(c, dmalloc(o.idx0, B * K));
+        HIPCHK(c, dmalloc(o.idx1, B * K));
+        HIPCHK(c, dmalloc(o.dist0, B * K));
+        HIPCHK(c, dmalloc(o.dist1, B * K));
+        HIPCHK(c, dmalloc(o.mfrom, B * K));
+        HIPCHK(c, dmalloc(o.mto, B * K));
+        HIPCHK(c, dmalloc(o.mcount, B));
+        HIPCHK(c, hipMemset(o.mcount, 0, B * 4));
+        HIPCHK(c, hipEventCreateWithFlags(&o.ev_detect, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&o.ev_match, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_m, hipStreamNonBlocking));
+    {
+        const char* e = getenv("MSLAM_HIP_OVERLAP_MATCH");
+        c->overlap_match = !(e && atoi(e) == 0);
+    }
+    select_set(c, 0);
     HIPCHK(c, hipDeviceSynchronize());
     return MSLAM_HIP_OK;
 }
@@ -510,6 +544,7 @@ constexpr int kMinChunk = 8; // do not cut batches into chunks smaller than this
 static int check_flags(mslam_hip_ctx* c)
 {
     uint32_t f = 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream_m));
     HIPCHK(c, hipMemcpyAsync(&f, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if(f == 0)
@@ -541,13 +576,23 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
     hipStream_t s = c->stream;
     c->timers_used = 0;
 
-    // carry the last frame of the previous batch into slot 0 (predecessor of the new frame 0)
+    // This batch goes into the other output set, so that a matcher still running on the previous batch (on
+    // its own stream) is not disturbed.  The set we are about to fill was last read by the matcher of two
+    // batches ago: wait for it.
     if(c->n_last > 0)
     {
+        const int prev = c->cur, nxt = prev ^ 1;
+        if(c->out[nxt].match_pending)
+        {
+            HIPCHK(c, hipStreamWaitEvent(s, c->out[nxt].ev_match, 0));
+            c->out[nxt].match_pending = false;
+        }
+        // carry the last frame of the previous batch into slot 0 (predecessor of the new frame 0)
         const size_t last = (size_t)c->n_last;
-        HIPCHK(c, hipMemcpyAsync(c->d_desc, c->d_desc + last * K * 32, K * 32, hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->d_count, c->d_count + last, 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->out[nxt].desc, c->out[prev].desc + last * K * 32, K * 32, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->out[nxt].count, c->out[prev].count + last, 4, hipMemcpyDeviceToDevice, s));
         c->have_prev = true;
+        select_set(c, nxt);
     }
     // Frames are independent until the matcher, so the batch is cut into chunks that run the same
     // kernel sequence on separate HIP streams: the latency-bound kernels of one chunk (quadtree, the
@@ -618,6 +663,7 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
         }
     }
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->out[c->cur].ev_detect, s));
     c->n_last = n_frames;
     return MSLAM_HIP_OK;
 }
@@ -712,7 +758,12 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
     const size_t K = (size_t)c->p.max_keypoints;
     const int first = (chain_previous && c->have_prev) ? 0 : 1; // first frame that has a predecessor
     const int n_pairs = c->n_last - first;
-    hipStream_t s = c->stream;
+    // the matcher runs on its own stream behind the detect batch it reads, so the next detect batch can
+    // start right away (with profiling on, everything stays on the context's stream)
+    const bool own = c->overlap_match && !c->profiling;
+    hipStream_t s = own ? c->stream_m : c->stream;
+    if(own)
+        HIPCHK(c, hipStreamWaitEvent(s, c->out[c->cur].ev_detect, 0));
     if(first == 1)
         HIPCHK(c, hipMemsetAsync(c->d_mcount, 0, 4, s));
     if(n_pairs > 0)
@@ -750,6 +801,11 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
         }
     }
     HIPCHK(c, hipGetLastError());
+    if(own)
+    {
+        HIPCHK(c, hipEventRecord(c->out[c->cur].ev_match, s));
+        c->out[c->cur].match_pending = true;
+    }
     return MSLAM_HIP_OK;
 }
 
@@ -935,6 +991,7 @@ int mslam_hip_copy_to_host(mslam_hip_ctx* c, void* dst_host, const void* src_dev
     ENTER(c);
     if(!dst_host || !src_dev)
         return fail(c, MSLAM_HIP_E_INVALID, "copy_to_host: null pointer");
+    HIPCHK(c, hipStreamSynchronize(c->stream_m));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
     return MSLAM_HIP_OK;

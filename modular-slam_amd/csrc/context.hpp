@@ -18,6 +18,22 @@ struct StageTimer
 };
 } // namespace mslam
 
+// One set of per-batch output buffers.  Two sets alternate so that the matcher of batch i (on its own
+// stream) can run while the detector of batch i+1 fills the other set.
+struct mslam_out_set
+{
+    float* xy = nullptr;
+    uint8_t* desc = nullptr;
+    int32_t* octave = nullptr;
+    float* angle = nullptr;
+    float* response = nullptr;
+    int32_t* count = nullptr;
+    int32_t *idx0 = nullptr, *idx1 = nullptr, *dist0 = nullptr, *dist1 = nullptr;
+    int32_t *mfrom = nullptr, *mto = nullptr, *mcount = nullptr;
+    hipEvent_t ev_detect = nullptr, ev_match = nullptr;
+    bool match_pending = false;
+};
+
 struct mslam_hip_ctx
 {
     mslam_hip_params p{};
@@ -54,6 +70,11 @@ struct mslam_hip_ctx
     mslam::QuadArgs quad{};
     uint32_t* d_flags = nullptr;
 
+    // two alternating output sets; the d_* members below alias the set of the last detect batch
+    mslam_out_set out[2];
+    int cur = 0;
+    hipStream_t stream_m = nullptr; // matcher stream
+    bool overlap_match = true;
     // outputs: slot 0 = last frame of the previous batch, slots 1..max_batch = current batch
     float* d_xy = nullptr;
     uint8_t* d_desc = nullptr;
