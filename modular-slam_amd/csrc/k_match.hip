@@ -23,6 +23,13 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
     return d;
 }
 
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // A train row is the same for every lane of a wave, so it is fetched with SCALAR loads (s_load_dwordx8
 // through the scalar cache) and used as an SGPR operand of the per-lane xor: no LDS staging, no vector
 // memory traffic in the loop.  Each lane owns QL queries; MW waves of a workgroup scan disjoint slices
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(64 * MW) void k_match_knn2(MatchArgs a)
             d = bcnt_acc(qb[u].z ^ t6, d);
             d = bcnt_acc(qb[u].w ^ t7, d);
             const uint32_t key = (d << 16) | (uint32_t)j;
-            best1[u] = min(max(best0[u], key), best1[u]);
+            best1[u] = med3_u32(best0[u], best1[u], key); // best0 <= best1: the median is the new runner-up
             best0[u] = min(best0[u], key);
         }
     };
