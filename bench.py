@@ -219,10 +219,10 @@ def main():
                     "stages_ms": {k: round(x, 4) for k, x in acc.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0}}
         if "match_knn2" in acc:
-            # the matcher is popcount-bound, not HBM-bound: 8 xor + 8 bcnt + 4 top-2 ops per pair
+            # the matcher is popcount-bound, not HBM-bound: 8 xor + 8 bcnt + 3 top-2 ops per pair
             pairs = B * (kp_b / B) ** 2
-            tops = pairs * 20 / (acc["match_knn2"] * 1e-3) / 1e12
-            roofline["match_valu"] = {"bound": "int-valu", "pairs_per_launch": int(pairs), "ops_per_pair": 20,
+            tops = pairs * 19 / (acc["match_knn2"] * 1e-3) / 1e12
+            roofline["match_valu"] = {"bound": "int-valu", "pairs_per_launch": int(pairs), "ops_per_pair": 19,
                                       "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2),
                                       "unit": "Tlane-op/s", "frac": round(tops / VALU_PEAK_TOPS, 3)}
         w, h, _ = ctx.level_geometry()

@@ -51,7 +51,7 @@ struct BowState
     int32_t* d_rn = nullptr;        // [RP]
     long long next_id = 0;
     // scoring outputs
-    double* d_contrib = nullptr;    // [B+1][cap][R] matched terms, ascending word order, entry index fastest
+    double* d_contrib = nullptr;    // [B+1][R][cap] matched terms of every (query, entry) pair, ascending word order
     int32_t* d_match_cnt = nullptr; // [B+1][R]
     double* d_scores = nullptr;     // [B+1][R]   score against entry (id_t - 1 - j), -1 when absent / no common word
     int32_t* d_best_entry = nullptr; // [B+1]
@@ -148,6 +148,11 @@ __global__ __launch_bounds__(VT) void k_bow_vector(const uint32_t* __restrict__ 
     uint32_t* ow = bwords + (size_t)(slot0 + frame) * cap;
     double* ov = bvalues + (size_t)(slot0 + frame) * cap;
 
+    // sort size: the smallest power of two (>= 64) holding this frame's n features
+    int np2 = 64;
+    while(np2 < n)
+        np2 <<= 1;
+    npow2 = min(npow2, np2);
     for(int i = tid; i < npow2; i += VT)
     {
         unsigned long long key = ~0ull;
@@ -264,7 +269,8 @@ __global__ __launch_bounds__(256) void k_bow_commit(const uint32_t* __restrict__
         rn[slot] = n;
 }
 
-constexpr int kScoreWaves = 4; // database entries scored per workgroup (one per wave)
+constexpr int kScoreBlocksPerFrame = 2; // the query hash is rebuilt per block; two blocks per frame keep 2 blocks/CU busy
+constexpr int kScoreWaves = 16; // waves per workgroup; the workgroup owns one query frame, each wave a share of the entries
 
 // L1Scoring::score of query vector `qslot + blockIdx.y` against the window of database entries that
 // precede it.  The query's words go into an LDS hash table once per workgroup; each wave then streams
@@ -277,22 +283,15 @@ __global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
     long long base_id, int per_frame_id, int R, int RP, int slots, double* __restrict__ contrib,
     int32_t* __restrict__ match_cnt)
 {
-    extern __shared__ uint32_t sm[]; // [slots] hash table of (index + 1), then [cap] query words
-    uint32_t* table = sm;
-    uint32_t* qw = sm + slots;
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm_raw[];
+    double* qv = reinterpret_cast<double*>(sm_raw);                     // [cap] query values
+    uint32_t* table = reinterpret_cast<uint32_t*>(qv + cap);            // [slots] hash table of (index + 1)
+    uint32_t* qw = table + slots;                                       // [cap] query words
 
     const int t = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = blockIdx.x * kScoreWaves + wave;
     const long long id_t = base_id + (per_frame_id ? t : 0); // entries with id < id_t are visible
-    if((long long)blockIdx.x * kScoreWaves >= id_t || blockIdx.x * kScoreWaves >= R)
-    {
-        // nothing visible in this group: mark absent
-        if(lane == 0 && j < R)
-            match_cnt[(size_t)(qslot + t) * R + j] = -1;
-        return;
-    }
     const uint32_t* w1 = bwords + (size_t)(qslot + t) * cap;
     const double* v1 = bvalues + (size_t)(qslot + t) * cap;
     const int n1 = bn[qslot + t];
@@ -301,7 +300,10 @@ __global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
     for(int i = tid; i < slots; i += 64 * kScoreWaves)
         table[i] = 0;
     for(int i = tid; i < n1; i += 64 * kScoreWaves)
+    {
         qw[i] = w1[i];
+        qv[i] = v1[i];
+    }
     __syncthreads();
     for(int i = tid; i < n1; i += 64 * kScoreWaves)
     {
@@ -311,26 +313,39 @@ __global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
     }
     __syncthreads();
 
-    const long long e_id = id_t - 1 - j;
-    if(j >= R)
-        return;
-    if(e_id >= 0)
+    for(int j = blockIdx.x * kScoreWaves + wave; j < R; j += gridDim.x * kScoreWaves)
     {
+        const long long e_id = id_t - 1 - j;
+        const size_t oj = (size_t)(qslot + t) * R + j;
+        if(e_id < 0)
+        {
+            if(lane == 0)
+                match_cnt[oj] = -1; // entry does not exist
+            continue;
+        }
         const int slot = (int)(e_id % RP);
         const uint32_t* w2 = rwords + (size_t)slot * cap;
         const double* v2 = rvalues + (size_t)slot * cap;
         const int n2 = rn[slot];
-        // matched terms are written, in ascending word order, to contrib[t][k][j] (entry index fastest)
-        double* out = contrib + (size_t)(qslot + t) * cap * R + j;
+        // matched terms are written, in ascending word order, to contrib[t][j][k]
+        double* out = contrib + oj * cap;
         uint32_t n_match = 0;
+        uint32_t word_n = lane < n2 ? w2[lane] : 0u; // the next chunk's loads are issued before this chunk is probed
+        double wi_n = lane < n2 ? v2[lane] : 0.0;
         for(int base = 0; base < n2; base += 64)
         {
             const int i = base + lane;
+            const uint32_t word = word_n;
+            const double wi = wi_n;
+            if(i + 64 < n2)
+            {
+                word_n = w2[i + 64];
+                wi_n = v2[i + 64];
+            }
             double c = 0;
             bool found = false;
             if(i < n2)
             {
-                const uint32_t word = w2[i];
                 uint32_t h = (word * 2654435761u) >> 7 & hmask;
                 for(;;)
                 {
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
                         break;
                     if(qw[e - 1] == word)
                     {
-                        const double vi = v1[e - 1], wi = v2[i];
+                        const double vi = qv[e - 1];
                         c = fabs(vi - wi) - fabs(vi) - fabs(wi);
                         found = true;
                         break;
@@ -349,15 +364,12 @@ __global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
             }
             const unsigned long long m = __ballot(found);
             if(found)
-                out[(size_t)(n_match + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) * R] = c;
+                out[n_match + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c;
             n_match += (uint32_t)__popcll(m);
         }
         if(lane == 0)
-            match_cnt[(size_t)(qslot + t) * R + j] = (int32_t)n_match;
-        return;
+            match_cnt[oj] = (int32_t)n_match;
     }
-    if(lane == 0)
-        match_cnt[(size_t)(qslot + t) * R + j] = -1; // entry does not exist
 }
 
 // Sequential, ascending-word-order sum of the matched terms: one LANE per (query, entry), so the 64
@@ -369,25 +381,27 @@ __global__ __launch_bounds__(64) void k_bow_sum(const double* __restrict__ contr
     const int j = blockIdx.x * 64 + threadIdx.x;
     if(j >= R)
         return;
-    const int n = match_cnt[(size_t)(qslot + t) * R + j];
-    const double* in = contrib + (size_t)(qslot + t) * cap * R + j;
+    const size_t oj = (size_t)(qslot + t) * R + j;
+    const int n = match_cnt[oj];
+    const double* in = contrib + oj * cap; // this lane's own row: consecutive addresses, L1-friendly
     double s = 0;
     int k = 0;
-    for(; k + 32 <= n; k += 32) // 32 loads in flight, then the 32 dependent adds in order
+    for(; k + 16 <= n; k += 16) // 16 loads in flight, then the 16 dependent adds in order
     {
-        double v[32];
+        double v[16];
 #pragma unroll
-        for(int u = 0; u < 32; ++u)
-            v[u] = in[(size_t)(k + u) * R];
+        for(int u = 0; u < 16; ++u)
+            v[u] = in[k + u];
 #pragma unroll
-        for(int u = 0; u < 32; ++u)
+        for(int u = 0; u < 16; ++u)
             s += v[u];
     }
     for(; k < n; ++k)
-        s += in[(size_t)k * R];
+        s += in[k];
     // Database::queryL1 only reports entries sharing a word with the query
-    scores[(size_t)(qslot + t) * R + j] = n > 0 ? -s / 2.0 : -1.0;
+    scores[oj] = n > 0 ? -s / 2.0 : -1.0;
 }
+
 // best entry per query: highest score, ties to the lower entry id (= the higher j)
 __global__ __launch_bounds__(64) void k_bow_best(const double* __restrict__ scores, int qslot, long long base_id,
                                                  int per_frame_id, int R, int32_t* __restrict__ best_entry,
@@ -719,12 +733,11 @@ static int bow_score_dev(mslam_hip_ctx* c, int qslot, int n_frames, long long ba
     int slots = 1024;
     while(slots < 2 * b->cap)
         slots <<= 1;
-    const size_t lds = (size_t)(slots + b->cap) * 4;
+    const size_t lds = (size_t)b->cap * 8 + (size_t)(slots + b->cap) * 4;
     if(lds > 48 * 1024)
         BHIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_score),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((b->R + kScoreWaves - 1) / kScoreWaves, n_frames);
-    hipLaunchKernelGGL(k_bow_score, grid, dim3(64 * kScoreWaves), lds, c->stream, b->d_bwords, b->d_bvalues, b->d_bn, qslot,
+    hipLaunchKernelGGL(k_bow_score, dim3(kScoreBlocksPerFrame, n_frames), dim3(64 * kScoreWaves), lds, c->stream, b->d_bwords, b->d_bvalues, b->d_bn, qslot,
                        b->cap, b->d_rwords, b->d_rvalues, b->d_rn, base_id, per_frame_id, b->R, b->RP, slots, b->d_contrib,
                        b->d_match_cnt);
     hipLaunchKernelGGL(k_bow_sum, dim3((b->R + 63) / 64, n_frames), dim3(64), 0, c->stream, b->d_contrib, b->d_match_cnt,
