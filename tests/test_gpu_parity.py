@@ -199,3 +199,40 @@ def test_backproject_batch_device(pkg, orc, synth_frames):
         rx, ro = orc.backproject(depth[i], det["xy"])
         assert np.array_equal(ok[i, :cnt[i]].astype(bool), ro) and np.array_equal(xyz[i, :cnt[i]], rx)
     c.close()
+
+
+def test_full_size_batch_properties(pkg, orc, synth_frames):
+    """cfg2-sized launch (250 frames in one batch): size-independent properties instead of a 250-frame oracle run —
+    identical frames give identical outputs wherever they sit in the batch, a frame matched against an identical
+    predecessor maps every keypoint to itself with distance 0, and spot-checked frames equal the oracle."""
+    import torch
+    B, K = 250, 4096
+    idx = np.arange(B) % 5                       # frames 0..4 repeated; frame t+5 == frame t
+    idx[101] = idx[100]                          # frame 101 == frame 100: identical consecutive frames
+    frames = np.ascontiguousarray(synth_frames[idx])
+    c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K)
+    c.detect_batch_dev(torch.from_numpy(frames).cuda().data_ptr(), B)
+    c.match_batch_dev(0.7, False)
+    c.sync()
+    v = c.batch_view()
+    cnt = pkg.read_device(c, v.count, (B,), np.int32)
+    desc = pkg.read_device(c, v.desc, (B, K, 32), np.uint8)
+    xy = pkg.read_device(c, v.xy, (B, K, 2), np.float32)
+    mc = pkg.read_device(c, v.match_count, (B,), np.int32)
+    mf = pkg.read_device(c, v.match_from, (B, K), np.int32)
+    mt = pkg.read_device(c, v.match_to, (B, K), np.int32)
+    for t in range(B):
+        r = idx[t]
+        assert cnt[t] == cnt[r] and np.array_equal(desc[t, :cnt[t]], desc[r, :cnt[r]])
+        assert np.array_equal(xy[t, :cnt[t]], xy[r, :cnt[r]])
+    for r in (0, 3):
+        ref = orc.detect(synth_frames[r], orc.params())
+        assert cnt[r] == len(ref["xy"]) and np.array_equal(desc[r, :cnt[r]], ref["desc"])
+    # identical predecessor: every query whose descriptor is unique in the frame matches itself
+    n = cnt[101]
+    assert mc[101] > 0.9 * n
+    assert np.array_equal(mf[101, :mc[101]], mt[101, :mc[101]])
+    # a regular pair equals the oracle
+    rf, rt = orc.match(desc[7, :cnt[7]], desc[6, :cnt[6]])
+    assert mc[7] == len(rf) and np.array_equal(mf[7, :mc[7]], rf) and np.array_equal(mt[7, :mc[7]], rt)
+    c.close()
