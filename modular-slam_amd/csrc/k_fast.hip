@@ -7,7 +7,8 @@
 // One 256-thread workgroup per (cell, frame).  The kernel is integer-VALU bound, so it is organised
 // to spend instructions only where corners can be:
 //   A. every tested pixel takes the 4-point compass test (a 9-arc always contains two adjacent
-//      compass points of one polarity); survivors are compacted into an LDS list with one ballot per row;
+//      compass points of one polarity), four pixels per lane with packed 16-bit compares on dword LDS
+//      reads; survivors are compacted into an LDS list with ballots;
 //   B. the list is processed densely (all 64 lanes busy): 16 circle reads and the arc score
 //        S = max(max_arc min(d), max_arc min(-d)) - 1,   d = centre - circle pixel,
 //      over the 16 arcs of 9 pixels, with 3-input min/max.  For a pixel that passes the 9-contiguous
@@ -22,8 +23,8 @@
 namespace mslam
 {
 
-constexpr int kTileP = 76; // tile row pitch in bytes: 19 dwords, column 0 = sub-image column -3 (dword aligned)
-constexpr int kTileX = 3;  // tile column of sub-image column 0
+constexpr int kTileP = 76; // tile row pitch in bytes: 19 dwords; tile dword q holds sub-image columns 4q-1 .. 4q+2,
+constexpr int kTileX = 1;  // i.e. tile byte = column + 1, so the tested columns 3+4i .. 6+4i are dword 1+i
 constexpr int kScP = 68;   // score-map row pitch
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kScP];
-    __shared__ uint16_t cand[64 * 64];
+    __shared__ uint16_t cand[64 * 64 + 2];
+    constexpr uint32_t kDump = 64 * 64; // write-only slot for rejected pixels
     __shared__ uint32_t bitmap[64 * 2];
     __shared__ uint32_t n_cand;
 
@@ -83,50 +85,93 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     if(tid == 0)
         n_cand = 0;
 
-    // stage the sub-image with aligned dword loads: x0 - 3 is a multiple of 4 (x0 = 19 + 64 j)
+    // stage the sub-image: aligned global dwords start at column x0 - 3 (x0 = 19 + 64 j), the LDS image is
+    // shifted by two bytes (v_alignbyte) so that the tested columns are dword aligned in LDS
     {
-        const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - kTileX);
+        const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - 3);
         const int n_dw = ch * 19;
         for(int i = tid; i < n_dw; i += 256)
         {
             const int r = i / 19, q = i - r * 19;
-            reinterpret_cast<uint32_t*>(tile)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 4 * q);
+            const uint32_t* gp = reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 4 * q);
+            reinterpret_cast<uint32_t*>(tile)[i] = __builtin_amdgcn_alignbyte(gp[1], gp[0], 2);
         }
     }
     __syncthreads();
 
-    const int x = lane + 3; // tested columns: 3 <= x < cw - 3
-    const bool col_ok = x < cw - 3;
     uint32_t total = 0;
     for(int pass = 0; pass < 2; ++pass)
     {
         const int thr = pass == 0 ? ini_thr : min_thr;
 
-        // ---- A. compass test + compaction
-#pragma unroll 1
-        for(int r = 0; r < 16; ++r)
+        // ---- A. compass test + compaction, four pixels per lane: a wave covers 4 rows x 64 columns per step.
+        //      Pixels are widened to u16 pairs and compared with packed 16-bit subtracts (sign bit = result).
         {
-            const int y = 3 + wave * 16 + r;
-            bool keep = false;
-            if(col_ok && y < ch - 3)
+            const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
+            const int i4 = lane & 15, sub = lane >> 4;
+            const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
+            // which of this lane's four columns 3+4i .. 6+4i are tested (x < cw - 3)
+            const int xl = 3 + 4 * i4;
+            const uint32_t colmask = (xl < cw - 3 ? 1u : 0u) | (xl + 1 < cw - 3 ? 2u : 0u) | (xl + 2 < cw - 3 ? 4u : 0u) |
+                                     (xl + 3 < cw - 3 ? 8u : 0u);
+#pragma unroll 1
+            for(int it = 0; it < 4; ++it)
             {
-                const uint8_t* p = &tile[y * kTileP + x + kTileX];
-                const int v = p[0];
-                const int hi = v + thr, lo = v - thr;
-                const int p0 = p[3 * kTileP], p4 = p[3], p8 = p[-3 * kTileP], p12 = p[-3];
-                const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
-                const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
-                keep = ((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12));
-            }
-            const unsigned long long b = __ballot(keep);
-            if(b != 0)
-            {
-                uint32_t base = 0;
-                if(lane == 0)
-                    base = atomicAdd(&n_cand, (uint32_t)__popcll(b));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if(keep)
-                    cand[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((y << 8) | x);
+                const int y = 3 + wave * 16 + it * 4 + sub;
+                uint32_t keep = 0;
+                if(colmask != 0 && y < ch - 3)
+                {
+                    const uint32_t* row = T + y * 19 + i4;
+                    const uint32_t L = row[0], C = row[1], R = row[2];
+                    const uint32_t U = row[1 - 3 * 19], D = row[1 + 3 * 19];
+                    const uint32_t Lf = __builtin_amdgcn_alignbyte(C, L, 1); // columns x-3 of the four pixels
+                    const uint32_t Rt = __builtin_amdgcn_alignbyte(R, C, 3); // columns x+3
+                    uint32_t k[2];
+#pragma unroll
+                    for(int h = 0; h < 2; ++h)
+                    {
+                        const uint32_t sel = h == 0 ? 0x0c010c00u : 0x0c030c02u; // bytes (0,1) or (2,3) as u16 lanes
+                        typedef short s16x2 __attribute__((ext_vector_type(2)));
+                        auto w = [&](uint32_t v) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, v, sel)); };
+                        const s16x2 t2 = __builtin_bit_cast(s16x2, thr2);
+                        const s16x2 cc = w(C), hi = cc + t2, lo = cc - t2;
+                        const s16x2 p0 = w(D), p4 = w(Rt), p8 = w(U), p12 = w(Lf);
+                        // sign bit set <=> brighter than c + t (hi - p < 0) / darker than c - t (p - lo < 0)
+                        const uint32_t b0 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p0)), b4 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p4));
+                        const uint32_t b8 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p8)), b12 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p12));
+                        const uint32_t d0 = __builtin_bit_cast(uint32_t, (s16x2)(p0 - lo)), d4 = __builtin_bit_cast(uint32_t, (s16x2)(p4 - lo));
+                        const uint32_t d8 = __builtin_bit_cast(uint32_t, (s16x2)(p8 - lo)), d12 = __builtin_bit_cast(uint32_t, (s16x2)(p12 - lo));
+                        k[h] = ((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12));
+                    }
+                    keep = (((k[0] >> 15) & 1u) | ((k[0] >> 30) & 2u) | ((k[1] >> 13) & 4u) | ((k[1] >> 28) & 8u)) & colmask;
+                }
+                // compaction: wave-wide inclusive scan of the per-lane counts with DPP adds (no LDS, no ballots);
+                // every lane then issues its four stores unconditionally, rejected pixels into a dump slot
+                const uint32_t cnt = (uint32_t)__popc(keep);
+                uint32_t inc = cnt;
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true); // row_shr:1
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true); // row_shr:2
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xE, true); // row_shr:4
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xC, true); // row_shr:8
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xA, 0xF, true); // row_bcast:15
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xC, 0xF, true); // row_bcast:31
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if(tot != 0)
+                {
+                    uint32_t base = 0;
+                    if(lane == 0)
+                        base = atomicAdd(&n_cand, tot);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    uint32_t pos = base + inc - cnt;
+                    const uint32_t yx = (uint32_t)((y << 8) | xl);
+                    cand[(keep & 1u) ? pos : kDump] = (uint16_t)yx;
+                    pos += keep & 1u;
+                    cand[(keep & 2u) ? pos : kDump] = (uint16_t)(yx + 1);
+                    pos += (keep >> 1) & 1u;
+                    cand[(keep & 4u) ? pos : kDump] = (uint16_t)(yx + 2);
+                    pos += (keep >> 2) & 1u;
+                    cand[(keep & 8u) ? pos : kDump] = (uint16_t)(yx + 3);
+                }
             }
         }
         __syncthreads();
