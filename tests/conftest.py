@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the HIP library, the host plugin and the oracle when a fresh checkout has none of them yet
+    (hipcc cross-compiles gfx950 without a GPU).  A prebuilt tree is left alone."""
+    need = [os.path.join(ROOT, "modular-slam_amd", "libmslam_hip.so"),
+            os.path.join(ROOT, "modular-slam_amd", "host", "libmslam_hip_plugin.so"),
+            os.path.join(ROOT, "oracle", "libmslam_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        graft.build()
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure)."""
