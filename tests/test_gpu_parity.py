@@ -236,3 +236,40 @@ def test_full_size_batch_properties(pkg, orc, synth_frames):
     rf, rt = orc.match(desc[7, :cnt[7]], desc[6, :cnt[6]])
     assert mc[7] == len(rf) and np.array_equal(mf[7, :mc[7]], rf) and np.array_equal(mt[7, :mc[7]], rt)
     c.close()
+
+
+@pytest.mark.parametrize("W,H,levels,scale,ini,mn,area", [
+    (240, 320, 4, 1.2, 20, 7, 1000),     # portrait: the reference's `delta_x = max_x - min_y` branch (:1045-1052)
+    (1000, 200, 3, 1.2, 20, 7, 500),     # very wide: five initial quadtree nodes
+    (400, 300, 5, 1.5, 20, 7, 1000),     # other pyramid scale
+    (512, 384, 3, 2.0, 30, 10, 2000),    # scale 2: widest resize windows, other FAST thresholds
+    (402, 301, 6, 1.3, 12, 12, 300),     # odd sizes, equal thresholds
+    (640, 480, 12, 1.1, 20, 7, 1000),    # many shallow levels
+    (641, 479, 1, 1.2, 20, 7, 100),      # single level, W % 4 != 0
+])
+def test_detect_parameter_sweep(pkg, orc, W, H, levels, scale, ini, mn, area):
+    import synth
+    f = synth.make_stream(1, W, H, seed=W + H)[0]
+    c = pkg.Context(width=W, height=H, n_levels=levels, scale_factor=scale, ini_fast_thr=ini, min_fast_thr=mn,
+                    min_node_area=area, max_keypoints=30000, max_candidates=65536)
+    got = c.detect(f, max_out=30000)
+    ref = orc.detect(f, orc.params(n_levels=levels, scale_factor=scale, ini_fast_thr=ini, min_fast_thr=mn, min_size=area))
+    assert len(ref["xy"]) > 20
+    assert_same_detection(got, ref)
+    c.close()
+
+
+def test_sparse_corners_use_fallback_threshold(pkg, orc):
+    """cells without any threshold-20 corner must fall back to threshold 7 (:922-926): a dark frame with a few
+    faint squares has corners only at the low threshold."""
+    img = np.full((480, 640, 3), 60, np.uint8)
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        x, y = int(rng.integers(40, 580)), int(rng.integers(40, 420))
+        img[y:y + 12, x:x + 12] = 60 + int(rng.integers(9, 18))     # contrast 9..17: below 20, above 7
+    img[200:230, 300:330] = 200                                       # one strong square: its cell stays at threshold 20
+    c = pkg.Context(width=640, height=480)
+    got, ref = c.detect(img), orc.detect(img, orc.params())
+    assert len(ref["xy"]) > 10 and ref["response"].min() < 20 <= ref["response"].max()
+    assert_same_detection(got, ref)
+    c.close()
