@@ -20,12 +20,10 @@ namespace mslam
 {
 
 constexpr int QT = 512;           // threads per workgroup
-constexpr int kLdsNodes = 2048;   // child counters live in LDS while the list is this short
 constexpr int kLdsKp = 2048;      // levels with at most this many candidates keep ALL working arrays in LDS
 constexpr int kMaxCellsPerLevel = 2048;
 constexpr int kMaxInitNodes = 64;
 constexpr int kMaxPasses = 40;
-constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 
 struct Scan
 {
@@ -119,16 +117,42 @@ __device__ __forceinline__ uint2 pack_node(int bx, int by, int ex, int ey)
     return make_uint2((uint32_t)bx | ((uint32_t)by << 16), (uint32_t)ex | ((uint32_t)ey << 16));
 }
 
+// Storage policy of the two instantiations.  The LDS one packs indices into 16 bits and the four child
+// counters of a node into two dwords so that two workgroups fit one CU (the passes are latency-bound,
+// so resident workgroups per CU is what sets the throughput); the global one is sized for any level.
+struct LdsStore
+{
+    using idx_t = uint16_t;
+    using info_t = uint8_t;
+    static constexpr bool kLds = true;
+    static __device__ __forceinline__ void cc_zero(uint32_t* cc, uint32_t pos) { cc[2 * pos] = 0, cc[2 * pos + 1] = 0; }
+    static __device__ __forceinline__ void cc_add(uint32_t* cc, uint32_t pos, int c) { atomicAdd(&cc[2 * pos + (c >> 1)], 1u << (16 * (c & 1))); }
+    static __device__ __forceinline__ uint32_t cc_get(const uint32_t* cc, uint32_t pos, int c) { return (cc[2 * pos + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu; }
+};
+struct GlobalStore
+{
+    using idx_t = uint32_t;
+    using info_t = uint32_t;
+    static constexpr bool kLds = false;
+    static __device__ __forceinline__ void cc_zero(uint32_t* cc, uint32_t pos) { cc[4 * pos] = 0, cc[4 * pos + 1] = 0, cc[4 * pos + 2] = 0, cc[4 * pos + 3] = 0; }
+    static __device__ __forceinline__ void cc_add(uint32_t* cc, uint32_t pos, int c) { atomicAdd(&cc[4 * pos + c], 1u); }
+    static __device__ __forceinline__ uint32_t cc_get(const uint32_t* cc, uint32_t pos, int c) { return ld_atomic(&cc[4 * pos + c]); }
+};
+
 // Everything after the candidate count is known.  Instantiated twice and force-inlined so that, in the
-// kLds instance, every working array is a known LDS object (ds_* instructions instead of flat_*).
-template <bool kLds>
+// LDS instance, every working array is a known LDS object (ds_* instructions instead of flat_*).
+template <class S>
 __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, const LevelGeom& lv, size_t frame,
                                          size_t slot, int tid, uint32_t N, int n_cells, const uint32_t* cell_off,
-                                         uint32_t* cand, uint32_t* g_cand, uint32_t* kp_node, uint2* nodes,
-                                         uint2* nodes2, uint32_t* ncnt, uint32_t* ncnt2, uint32_t* ninfo,
-                                         uint32_t* nbase, uint32_t* lds_cc, uint32_t* g_cc, uint32_t* sel, Scan& scan,
-                                         Scan& scan2, uint32_t* init_cnt, uint32_t* init_pos, uint32_t& sh_n)
+                                         uint32_t* cand, uint32_t* g_cand, typename S::idx_t* kp_node, uint2* nodes,
+                                         uint2* nodes2, typename S::idx_t* ncnt, typename S::idx_t* ncnt2,
+                                         typename S::info_t* ninfo, typename S::idx_t* nbase, uint32_t* cc,
+                                         uint32_t* best, uint32_t* sel, Scan& scan, Scan& scan2, uint32_t* init_cnt,
+                                         uint32_t* init_pos, uint32_t& sh_n)
 {
+    using idx_t = typename S::idx_t;
+    constexpr uint32_t kNoNode = (uint32_t)(idx_t)~(idx_t)0;
+
     const uint32_t* ckp = a.cell_kp + (frame * g.n_cells + lv.cell_base) * (size_t)kCellCap;
     for(uint32_t j = tid; j < N; j += QT)
     {
@@ -143,9 +167,10 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
         }
         const uint32_t v = ckp[(size_t)lo * kCellCap + (j - cell_off[lo])];
         cand[j] = v;
-        if(kLds)
+        if(S::kLds)
             g_cand[j] = v; // the global copy is kept for mslam_hip_debug_read
     }
+    __syncthreads(); // cell_off may share storage with arrays written below
 
     // ---- 1. initial nodes (:1025-1105)
     const int n_init = lv.nxg * lv.nyg;
@@ -161,10 +186,10 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
         if(idx < (unsigned)n_init)
         {
             atomicAdd(&init_cnt[idx], 1u);
-            kp_node[k] = idx;
+            kp_node[k] = (idx_t)idx;
         }
         else
-            kp_node[k] = kNoNode;
+            kp_node[k] = (idx_t)kNoNode;
     }
     __syncthreads();
     if(tid == 0)
@@ -178,7 +203,7 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
                 const int ix = i % lv.nxg, iy = i / lv.nxg;
                 nodes[n0] = pack_node((int)(lv.delta_x * ix), (int)(lv.delta_y * iy), (int)(lv.delta_x * (ix + 1)),
                                       (int)(lv.delta_y * (iy + 1)));
-                ncnt[n0] = init_cnt[i];
+                ncnt[n0] = (idx_t)init_cnt[i];
                 ++n0;
             }
         }
@@ -189,7 +214,7 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
     {
         const uint32_t idx = kp_node[k];
         if(idx != kNoNode)
-            kp_node[k] = init_pos[idx];
+            kp_node[k] = (idx_t)init_pos[idx];
     }
     uint32_t n = sh_n;
     __syncthreads();
@@ -200,22 +225,16 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
     bool converged = false;
     for(int pass = 0; pass < kMaxPasses && n > 0; ++pass)
     {
-        uint32_t* cc = (kLds || n <= (uint32_t)kLdsNodes) ? lds_cc : g_cc;
         // a. which nodes divide (:1002)
         for(uint32_t pos = tid; pos < n; pos += QT)
         {
             int bx, by, ex, ey;
             unpack_node(nodes[pos], bx, by, ex, ey);
             const unsigned area = (unsigned)((ex - bx) * (ey - by));
-            const bool keep = ncnt[pos] == 1u || __fmul_rn(__fmul_rn((float)area, sf), sf) <= min_size_f;
+            const bool keep = (uint32_t)ncnt[pos] == 1u || __fmul_rn(__fmul_rn((float)area, sf), sf) <= min_size_f;
             ninfo[pos] = keep ? 0u : 1u;
             if(!keep)
-            {
-                cc[4 * pos + 0] = 0;
-                cc[4 * pos + 1] = 0;
-                cc[4 * pos + 2] = 0;
-                cc[4 * pos + 3] = 0;
-            }
+                S::cc_zero(cc, pos);
         }
         __syncthreads();
         // b. count keypoints per child (:340-352)
@@ -228,8 +247,7 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
             unpack_node(nodes[pos], bx, by, ex, ey);
             const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1); // cvCeil(d/2.0)
             const uint32_t p = cand[k];
-            const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
-            atomicAdd(&cc[4 * pos + c], 1u);
+            S::cc_add(cc, pos, (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0));
         }
         __syncthreads();
         // c. list positions after this pass
@@ -243,8 +261,8 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
                 div = ninfo[pos] & 1u;
                 if(div)
                 {
-                    mask = (ld_atomic(&cc[4 * pos + 0]) ? 1u : 0u) | (ld_atomic(&cc[4 * pos + 1]) ? 2u : 0u) |
-                           (ld_atomic(&cc[4 * pos + 2]) ? 4u : 0u) | (ld_atomic(&cc[4 * pos + 3]) ? 8u : 0u);
+                    mask = (S::cc_get(cc, pos, 0) ? 1u : 0u) | (S::cc_get(cc, pos, 1) ? 2u : 0u) |
+                           (S::cc_get(cc, pos, 2) ? 4u : 0u) | (S::cc_get(cc, pos, 3) ? 8u : 0u);
                     nchild = (uint32_t)__popc(mask);
                 }
                 else
@@ -254,8 +272,8 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
             block_excl_scan2(nchild, und, scan, scan2, exD, exU, totD, totU);
             if(pos < n)
             {
-                ninfo[pos] = div | (mask << 1);
-                nbase[pos] = div ? D + exD : U + exU;
+                ninfo[pos] = (typename S::info_t)(div | (mask << 1));
+                nbase[pos] = (idx_t)(div ? D + exD : U + exU);
             }
             D += totD;
             U += totU;
@@ -272,17 +290,17 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
                 int bx, by, ex, ey;
                 unpack_node(nodes[pos], bx, by, ex, ey);
                 const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
-                const uint32_t first = T - 1 - nbase[pos];
+                const uint32_t first = T - 1 - (uint32_t)nbase[pos];
                 const uint32_t mask = info >> 1;
                 uint32_t r = 0;
-                if(mask & 1u) { nodes2[first - r] = pack_node(bx, by, cx, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 0]); ++r; }
-                if(mask & 2u) { nodes2[first - r] = pack_node(cx, by, ex, cy); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 1]); ++r; }
-                if(mask & 4u) { nodes2[first - r] = pack_node(bx, cy, cx, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 2]); ++r; }
-                if(mask & 8u) { nodes2[first - r] = pack_node(cx, cy, ex, ey); ncnt2[first - r] = ld_atomic(&cc[4 * pos + 3]); ++r; }
+                if(mask & 1u) { nodes2[first - r] = pack_node(bx, by, cx, cy); ncnt2[first - r] = (idx_t)S::cc_get(cc, pos, 0); ++r; }
+                if(mask & 2u) { nodes2[first - r] = pack_node(cx, by, ex, cy); ncnt2[first - r] = (idx_t)S::cc_get(cc, pos, 1); ++r; }
+                if(mask & 4u) { nodes2[first - r] = pack_node(bx, cy, cx, ey); ncnt2[first - r] = (idx_t)S::cc_get(cc, pos, 2); ++r; }
+                if(mask & 8u) { nodes2[first - r] = pack_node(cx, cy, ex, ey); ncnt2[first - r] = (idx_t)S::cc_get(cc, pos, 3); ++r; }
             }
             else
             {
-                const uint32_t np = T + nbase[pos];
+                const uint32_t np = T + (uint32_t)nbase[pos];
                 nodes2[np] = nodes[pos];
                 ncnt2[np] = ncnt[pos];
             }
@@ -301,16 +319,16 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
                 const int cx = bx + ((ex - bx + 1) >> 1), cy = by + ((ey - by + 1) >> 1);
                 const uint32_t p = cand[k];
                 const int c = (cx <= kp_x(p) ? 1 : 0) + (cy <= kp_y(p) ? 2 : 0);
-                np = T - 1 - nbase[pos] - (uint32_t)__popc((info >> 1) & ((1u << c) - 1u));
+                np = T - 1 - (uint32_t)nbase[pos] - (uint32_t)__popc((info >> 1) & ((1u << c) - 1u));
             }
             else
-                np = T + nbase[pos];
-            kp_node[k] = np;
+                np = T + (uint32_t)nbase[pos];
+            kp_node[k] = (idx_t)np;
         }
         __syncthreads();
         {
             uint2* t = nodes; nodes = nodes2; nodes2 = t;
-            uint32_t* u = ncnt; ncnt = ncnt2; ncnt2 = u;
+            idx_t* u = ncnt; ncnt = ncnt2; ncnt2 = u;
         }
         const uint32_t n2 = T + U;
         const bool same = n2 == n; // :1016-1019 — the pass's effects stay even when it is the last
@@ -325,7 +343,6 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
         atomicOr(a.flags, kFlagQuadNoConverge);
 
     // ---- 3. winner per node, emitted in list order (:1128-1155)
-    uint32_t* best = nbase;
     for(uint32_t pos = tid; pos < n; pos += QT)
         best[pos] = 0;
     __syncthreads();
@@ -339,7 +356,7 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
     __syncthreads();
     for(uint32_t pos = tid; pos < n; pos += QT)
     {
-        const uint32_t k = 0xFFFFFFu - (ld_atomic(&best[pos]) & 0xFFFFFFu);
+        const uint32_t k = 0xFFFFFFu - ((S::kLds ? best[pos] : ld_atomic(&best[pos])) & 0xFFFFFFu);
         sel[pos] = cand[k];
     }
     if(tid == 0)
@@ -349,16 +366,17 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
 __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
 {
     __shared__ Scan scan, scan2;
-    __shared__ uint32_t cell_off[kMaxCellsPerLevel + 1];
-    __shared__ uint32_t lds_cc[kLdsNodes * 4];
-    // LDS working set for small levels (the common case): the passes are latency-bound, and an LDS
-    // round trip is ~10x shorter than an L2 one.  Larger levels fall back to the global scratch arrays.
-    __shared__ uint32_t l_cand[kLdsKp], l_kp_node[kLdsKp], l_ncnt_a[kLdsKp], l_ncnt_b[kLdsKp], l_ninfo[kLdsKp],
-        l_nbase[kLdsKp];
-    __shared__ uint2 l_nodes_a[kLdsKp], l_nodes_b[kLdsKp];
+    // LDS working set of the common case (N <= kLdsKp): 74 KB, so two workgroups share a CU.
+    __shared__ uint32_t l_cand[kLdsKp];
+    __shared__ uint2 l_nodes_a[kLdsKp], l_nodes_b[kLdsKp]; // l_nodes_b doubles as the cell offset table of step 0
+    __shared__ uint32_t l_cc[kLdsKp * 2];                   // packed child counters; reused for the winners
+    __shared__ uint16_t l_kp_node[kLdsKp], l_ncnt_a[kLdsKp], l_ncnt_b[kLdsKp], l_nbase[kLdsKp];
+    __shared__ uint8_t l_ninfo[kLdsKp];
     __shared__ uint32_t init_cnt[kMaxInitNodes];
     __shared__ uint32_t init_pos[kMaxInitNodes];
     __shared__ uint32_t sh_n;
+    static_assert(sizeof(l_nodes_b) >= (kMaxCellsPerLevel + 1) * sizeof(uint32_t), "cell offsets must fit");
+    uint32_t* cell_off = reinterpret_cast<uint32_t*>(l_nodes_b);
 
     const int level = blockIdx.x;
     const size_t frame = blockIdx.y + g.frame0;
@@ -368,14 +386,6 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
     const size_t cap = (size_t)a.cand_cap;
     uint32_t* cand = a.cand + slot * cap;
     uint32_t* sel = a.sel + slot * cap;
-    uint32_t* kp_node = a.kp_node + slot * cap;
-    uint2* nodes = a.nodes_a + slot * cap;
-    uint2* nodes2 = a.nodes_b + slot * cap;
-    uint32_t* ncnt = a.ncnt_a + slot * cap;
-    uint32_t* ncnt2 = a.ncnt_b + slot * cap;
-    uint32_t* g_cc = a.child_cnt + slot * cap * 4;
-    uint32_t* ninfo = a.ninfo + slot * cap;
-    uint32_t* nbase = a.best + slot * cap; // doubles as "new base position" during passes
 
     // ---- 0. gather this level's candidates in the reference's order: cells row-major, then the
     //         row-major order inside each cell (:878-951)
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
     if(tid == 0)
         cell_off[n_cells] = running;
     __syncthreads();
-    uint32_t N = running;
+    const uint32_t N = running;
     if(N > (uint32_t)a.cand_cap)
     {
         if(tid == 0)
@@ -415,11 +425,14 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
         return;
     }
     if(N <= (uint32_t)kLdsKp)
-        quad_run<true>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, l_cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
-                       l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, lds_cc, g_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
+        quad_run<LdsStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, l_cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
+                           l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, l_cc, l_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
     else
-        quad_run<false>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, kp_node, nodes, nodes2, ncnt, ncnt2,
-                        ninfo, nbase, lds_cc, g_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
+        quad_run<GlobalStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, a.kp_node + slot * cap,
+                              a.nodes_a + slot * cap, a.nodes_b + slot * cap, a.ncnt_a + slot * cap,
+                              a.ncnt_b + slot * cap, a.ninfo + slot * cap, a.best + slot * cap,
+                              a.child_cnt + slot * cap * 4, a.best + slot * cap, sel, scan, scan2, init_cnt, init_pos,
+                              sh_n);
 }
 
 void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_frames, hipStream_t s)
