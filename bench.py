@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--voc-levels", type=int, default=6, help="vocabulary depth L (k=10): 6 -> 1e6 words")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU run) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="frames of the stream timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=500, help="frames of the stream timed on the CPU oracle")
     return ap.parse_args()
 
 
@@ -169,6 +169,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    ctx.set_profiling(2)  # HIP events around the matcher kernel, in place on its own stream, during the timed steps
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
@@ -177,6 +178,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    match_ms_timed = [ms for _, ms in ctx.stage_times()]  # one entry per timed step
+    ctx.set_profiling(0)
 
     # units processed: keypoints extracted (and matched against the previous frame) in the timed steps
     counts_per_batch = []
@@ -209,6 +212,8 @@ def main():
         ctx.set_profiling(False)
         kp_b, cand_b = counts_per_batch[0], cand_per_batch[0]
         sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)
+        if match_ms_timed:
+            acc["match_knn2"] = float(np.mean(match_ms_timed))  # measured over the timed region itself
         dom = max(acc, key=acc.get)
         launches = 7 if dom == "resize" else 1
         achieved = sb[dom] / (acc[dom] * 1e-3) / 1e9
@@ -216,6 +221,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, launches, B),
                     "launches_per_step": launches, "avg_ms": round(acc[dom], 4),
                     "algorithmic_bytes_per_launch": sb[dom] // launches,
+                    "timing": "match_knn2: HIP events on its stream inside the timed region (%d launches); other stages: "
+                              "HIP events in a serialised pass after it" % len(match_ms_timed),
                     "stages_ms": {k: round(x, 4) for k, x in acc.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0}}
         if "match_knn2" in acc:

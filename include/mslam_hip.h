@@ -209,8 +209,10 @@ int mslam_hip_debug_read(mslam_hip_ctx* ctx, int what, int frame, int level, voi
 /* Synchronise the context's stream, then copy `bytes` from a device pointer (e.g. out of a view) to host memory. */
 int mslam_hip_copy_to_host(mslam_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
-/* Per-stage device time (ms) of the last mslam_hip_detect_batch_dev / match_batch_dev when profiling
- * is enabled (HIP events on the context's stream).  names/ms hold up to cap entries. */
+/* Device timing with HIP events.  enable = 1: every stage of the last detect/match/bow batch, with
+ * everything serialised on the context's stream (kernel-by-kernel analysis).  enable = 2: only the matcher
+ * kernel, timed in place on the stream it runs on without changing the schedule; entries accumulate over
+ * calls until they are read.  enable = 0: off.  names/ms hold up to cap entries. */
 int mslam_hip_set_profiling(mslam_hip_ctx* ctx, int enable);
 int mslam_hip_get_stage_times(mslam_hip_ctx* ctx, const char** names, float* ms, int cap, int* n);
 

@@ -302,13 +302,14 @@ class Context:
         return out[:n.value].copy()
 
     def set_profiling(self, enable):
-        self._chk(self.L.mslam_hip_set_profiling(self._h, int(bool(enable))))
+        """0 = off, 1/True = every stage (serialised), 2 = the matcher only, in place."""
+        self._chk(self.L.mslam_hip_set_profiling(self._h, int(enable)))
 
-    def stage_times(self):
-        names = (C.c_char_p * 32)()
-        ms = (C.c_float * 32)()
+    def stage_times(self, cap=256):
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
         n = C.c_int(0)
-        self._chk(self.L.mslam_hip_get_stage_times(self._h, names, ms, 32, C.byref(n)))
+        self._chk(self.L.mslam_hip_get_stage_times(self._h, names, ms, cap, C.byref(n)))
         return [(names[i].decode(), ms[i]) for i in range(n.value)]
 
 

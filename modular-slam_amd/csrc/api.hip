@@ -574,7 +574,8 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
     const Geometry& g = c->geom;
     const size_t K = (size_t)c->p.max_keypoints;
     hipStream_t s = c->stream;
-    c->timers_used = 0;
+    if(!c->inplace_timing)
+        c->timers_used = 0;
 
     // This batch goes into the other output set, so that a matcher still running on the previous batch (on
     // its own stream) is not disturbed.  The set we are about to fill was last read by the matcher of two
@@ -780,6 +781,23 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
         m.idx1 = c->d_idx1 + (size_t)first * K;
         m.dist0 = c->d_dist0 + (size_t)first * K;
         m.dist1 = c->d_dist1 + (size_t)first * K;
+        if(c->inplace_timing && !c->profiling)
+        {
+            // in-place timing of the dominant kernel on the stream it runs on (bench.py's roofline)
+            if(c->timers_used == c->timers.size())
+            {
+                StageTimer nt{"match_knn2", nullptr, nullptr};
+                HIPCHK(c, hipEventCreate(&nt.start));
+                HIPCHK(c, hipEventCreate(&nt.stop));
+                c->timers.push_back(nt);
+            }
+            StageTimer& t = c->timers[c->timers_used++];
+            t.name = "match_knn2";
+            HIPCHK(c, hipEventRecord(t.start, s));
+            launch_match_knn2(m, n_pairs, s);
+            HIPCHK(c, hipEventRecord(t.stop, s));
+        }
+        else
         {
             StageScope t(c, "match_knn2");
             launch_match_knn2(m, n_pairs, s);
@@ -1001,7 +1019,8 @@ int mslam_hip_set_profiling(mslam_hip_ctx* c, int enable)
 {
     if(!c)
         return MSLAM_HIP_E_INVALID;
-    c->profiling = enable != 0;
+    c->profiling = enable == 1;
+    c->inplace_timing = enable == 2;
     c->timers_used = 0;
     return MSLAM_HIP_OK;
 }
@@ -1011,6 +1030,7 @@ int mslam_hip_get_stage_times(mslam_hip_ctx* c, const char** names, float* ms, i
     ENTER(c);
     if(!n)
         return fail(c, MSLAM_HIP_E_INVALID, "get_stage_times: null output");
+    HIPCHK(c, hipStreamSynchronize(c->stream_m));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int k = 0;
     for(size_t i = 0; i < c->timers_used && k < cap; ++i, ++k)
@@ -1023,6 +1043,8 @@ int mslam_hip_get_stage_times(mslam_hip_ctx* c, const char** names, float* ms, i
             ms[k] = t;
     }
     *n = k;
+    if(c->inplace_timing)
+        c->timers_used = 0; // entries accumulate across calls in this mode; reading them starts a new window
     return MSLAM_HIP_OK;
 }
 

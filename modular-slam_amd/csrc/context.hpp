@@ -99,7 +99,8 @@ struct mslam_hip_ctx
 
     mslam::BowState* bow = nullptr;
 
-    bool profiling = false;
+    bool profiling = false;      // mode 1: every stage timed, everything serialised on the context's stream
+    bool inplace_timing = false; // mode 2: only the matcher is timed, in place on the stream it runs on
     std::vector<mslam::StageTimer> timers;
     size_t timers_used = 0;
 };

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Write tests/golden/*.npz: the oracle's outputs for the reference's two bundled frames and two
+"""(lives under tests/ because it drives the oracle, which only tests may do)
+Write tests/golden/*.npz: the oracle's outputs for the reference's two bundled frames and two
 seeded synthetic frames ("restatement goldens, OpenCV parity unverified" — SURVEY.md §8c).  They pin
 the oracle against regressions and give the GPU tests fixed expected bytes."""
 import os, sys, zlib
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as graft
 import synth
