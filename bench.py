@@ -212,6 +212,7 @@ def main():
         ctx.set_profiling(False)
         kp_b, cand_b = counts_per_batch[0], cand_per_batch[0]
         sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)
+        serialized = dict(acc)
         if match_ms_timed:
             acc["match_knn2"] = float(np.mean(match_ms_timed))  # measured over the timed region itself
         dom = max(acc, key=acc.get)
@@ -224,6 +225,7 @@ def main():
                     "timing": "match_knn2: HIP events on its stream inside the timed region (%d launches); other stages: "
                               "HIP events in a serialised pass after it" % len(match_ms_timed),
                     "stages_ms": {k: round(x, 4) for k, x in acc.items()},
+                    "stages_ms_serialized": {k: round(x, 4) for k, x in serialized.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0}}
         if "match_knn2" in acc:
             # the matcher is popcount-bound, not HBM-bound: 8 xor + 8 bcnt + 3 top-2 ops per pair

@@ -131,6 +131,7 @@ struct MatchArgs
     int32_t* idx1;
     int32_t* dist0;
     int32_t* dist1;
+    int n_pairs = 0, wg_per_pair = 0; // filled in by the launcher
 };
 void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s);
 // ratio test + ordered compaction (orb_feature.cpp:99-114).  thr[d1] = largest d0 accepted + 1.
