@@ -30,11 +30,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # integer vector ALU: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (a wave64 VALU op issues over 4 cycles; the
-# 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).  Measured: the matcher loop sustains ~82 % of it.
+# 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md, matrix cores)
 STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "mslam::k_resize_quad", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur", "describe": "mslam::k_describe",
-                "match_knn2": "void mslam::k_match_knn2<8, 1, 8>", "ratio_compact": "mslam::k_ratio_compact"}
+                "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact"}
 
 
 def pmc_traffic(stage, launches, frames_per_launch):
@@ -228,12 +229,18 @@ def main():
                     "stages_ms_serialized": {k: round(x, 4) for k, x in serialized.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0}}
         if "match_knn2" in acc:
-            # the matcher is popcount-bound, not HBM-bound: 8 xor + 8 bcnt + 3 top-2 ops per pair
+            # the matcher is not HBM-bound.  Its distances run on the matrix cores as FP4 +-1 dot
+            # products (2*256 flop per pair, dense FP4 peak ~10 PFLOP/s); its top-2 selection is one v_med3 + one
+            # v_max per pair on the VALU (34 lane-ops per 16 pairs), which is the pipe that bounds it.
             pairs = B * (kp_b / B) ** 2
-            tops = pairs * 19 / (acc["match_knn2"] * 1e-3) / 1e12
-            roofline["match_valu"] = {"bound": "int-valu", "pairs_per_launch": int(pairs), "ops_per_pair": 19,
-                                      "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2),
-                                      "unit": "Tlane-op/s", "frac": round(tops / VALU_PEAK_TOPS, 3)}
+            t_s = acc["match_knn2"] * 1e-3
+            roofline["match_mfma"] = {"bound": "mfma", "dtype": "fp4 (+-1, exact)", "pairs_per_launch": int(pairs),
+                                      "achieved": round(pairs * 512 / t_s / 1e12, 1), "peak": MFMA_FP4_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": round(pairs * 512 / t_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)}
+            tops = pairs * (34 / 16) / t_s / 1e12
+            roofline["match_valu"] = {"bound": "valu-issue", "ops_per_pair": 34 / 16, "achieved": round(tops, 2),
+                                      "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
+                                      "frac": round(tops / VALU_PEAK_TOPS, 3)}
         w, h, _ = ctx.level_geometry()
         P = sum(x * y for x, y in zip(w, h))
         extract_bytes = 3 * a.width * a.height + 2 * P + 48 * (kp_b / B)

@@ -777,6 +777,7 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
         m.from_cnt = c->d_count + first + 1;
         m.to_cnt = c->d_count + first;
         m.cap = c->p.max_keypoints;
+        m.cap_from = c->p.max_keypoints;
         m.idx0 = c->d_idx0 + (size_t)first * K;
         m.idx1 = c->d_idx1 + (size_t)first * K;
         m.dist0 = c->d_dist0 + (size_t)first * K;

@@ -4,13 +4,14 @@
 // BFMatcher(NORM_HAMMING).knnMatch(query = to, train = from, k = 2) then the ratio test and the
 // (fromIndex = trainIdx, toIndex = queryIdx) output in query order.
 //
-// k_match_knn2: one lane owns one query descriptor (8 dwords in registers); train rows arrive through
-// the scalar unit (see the kernel).  On equal distances the lower train index ranks first — exactly
-// batchDistance's insertion rule (strict `<` on insertion while scanning train rows in ascending order).
-// Not HBM-bound: inputs are 2*K*32 bytes against K^2 popcount-compares.
+// Two kernels with identical results.  k_match_knn2_fp4 (the one that normally runs) computes the
+// distances on the matrix cores; k_match_knn2 is the xor/popcount form (one lane owns one query, train
+// rows arrive through the scalar unit) kept for train sets beyond the matrix-core kernel's index range.
+// On equal distances the lower train index ranks first — exactly batchDistance's insertion rule (strict
+// `<` on insertion while scanning train rows in ascending order).
+// Not HBM-bound: inputs are 2*K*32 bytes against K^2 distance evaluations.
 #include "common.hpp"
 #include <climits>
-#include <cstdlib>
 
 namespace mslam
 {
@@ -150,36 +151,37 @@ static void launch_variant(MatchArgs a, int n_pairs, hipStream_t s)
 
 
 // ---------------------------------------------------------------------------------------------------
-// MFMA form of the same search.  With every descriptor bit b expanded to the i8 value 2b-1, the i8 dot
-// product of two descriptors is 256 - 2*hamming, exactly (integers, i32 accumulate), so a 32x32 tile of
-// distances is 8 v_mfma_i32_32x32x32_i8 instead of 32*32*16 xor/popcount lane-ops.  Queries are the B
-// operand: the accumulator then has ONE query per lane column and 16 train rows in the lane's 16
-// registers, so the running top-2 of a query stays in its lane (2 lanes per query, merged at the end).
-//   key of (query, train j) = (dot + 257) << 16 | age,   age = 32*(tiles scanned after j's tile) + 31 - (j & 31)
-// larger key = smaller distance, then smaller train index: the order of batchDistance's insertion rule.
-// The accumulator is initialised to 257 so that valid keys are >= 1 << 16 and 0 means "no neighbour".
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+// Matrix-core form of the same search.  With every descriptor bit b expanded to the FP4 (E2M1) value 2b-1,
+// the dot product of two descriptors is 256 - 2*hamming, and v_mfma_scale_f32_32x32x64_f8f6f4 computes it
+// exactly (products +-1, f32 accumulation of integers below 2^24): a 32x32 tile of distances is 4 MFMAs
+// instead of 32*32*16 xor/popcount lane-operations.  The block scale of the query operand is 2^14, and the
+// accumulator starts at 257 * 2^14 + (31 - row), so what the matrix core delivers IS the sort key
+//   key(query, train j) = (dot + 257) * 2^14 + age,   age = 32 * (tiles scanned after j's tile) + 31 - (j & 31)
+// (larger key = smaller distance, then smaller train index: batchDistance's insertion order) and the VALU
+// only does the running top-2: one v_med3 + one v_max per pair, on the f32 bit patterns (positive floats
+// order like unsigned integers).  Keys below 2^14 mean "no neighbour".  The age field limits this kernel
+// to 16352 train rows; larger sets take the VALU kernel above.
+// Queries are the B operand: the accumulator then has ONE query per lane column and 16 train rows in the
+// lane's 16 registers, so a query's top-2 stays in its lane (two lanes per query, merged at the end).
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int MM_TROW = 272; // bytes of one expanded train row in LDS: 256 + 16 so that a fragment read is conflict-free
-
-__device__ __forceinline__ uint32_t lshl_add(uint32_t x, uint32_t sh, uint32_t y)
-{
-    return (x << sh) + y; // v_lshl_add_u32
-}
+constexpr int MM_TROW = 144;          // bytes of one expanded train row in LDS: 128 + 16 (conflict-free fragment reads)
+constexpr int MM_MAX_TRAIN = 16352;   // 32 * 511: the age field is 14 bits
+constexpr float MM_KEY_UNIT = 16384.f;
 
 template <int QT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_match_knn2_mfma(MatchArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_match_knn2_fp4(MatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[2][32 * MM_TROW];
-    __shared__ uint2 lut[256]; // byte -> its 8 bits as i8 +1 / -1
+    __shared__ uint32_t lut[256]; // byte -> its 8 bits as FP4 +1.0 (0x2) / -1.0 (0xA)
 
     // XCD-aware mapping, as in k_match_knn2: every workgroup of a pair runs on the XCD (id & 7)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pair = (slot / a.wg_per_pair) * 8 + xcd;
     if(pair >= a.n_pairs)
         return;
-    const int n_from = min(a.from_cnt ? a.from_cnt[pair] : a.n_from_fixed, 65535);
+    const int n_from = min(a.from_cnt ? a.from_cnt[pair] : a.n_from_fixed, MM_MAX_TRAIN);
     const int n_to = min(a.to_cnt ? a.to_cnt[pair] : a.n_to_fixed, a.cap);
     const int q0 = (slot % a.wg_per_pair) * (128 * QT);
     if(q0 >= n_to)
@@ -189,42 +191,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const uint32_t* __restrict__ from =
         reinterpret_cast<const uint32_t*>(a.from_desc + (long long)pair * a.from_stride);
     const uint8_t* to = a.to_desc + (long long)pair * a.to_stride;
-
-    {
-        auto spread = [](uint32_t x4) { // 4 bits -> 4 bytes of +1 / -1
-            const uint32_t nb = ((x4 ^ 15u) * 0x00204081u) & 0x01010101u; // 1 where the bit is 0
-            return ((nb << 8) - nb) | 0x01010101u;                         // 0xFF there, 0x01 elsewhere
-        };
-        lut[tid] = make_uint2(spread(tid & 15), spread(tid >> 4));
-    }
-    __syncthreads();
-
-    // B fragments: lane (r, h) holds bits [32 s + 16 h, +16) of query r for k-step s
-    v4i b[QT][8];
-#pragma unroll
-    for(int u = 0; u < QT; ++u)
-    {
-        const int q = q0 + (wave * QT + u) * 32 + r;
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if(q < n_to)
-        {
-            const uint4* qp = reinterpret_cast<const uint4*>(to + (size_t)q * 32);
-            lo = qp[0];
-            hi = qp[1];
-        }
-        const uint32_t dw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for(int s = 0; s < 8; ++s)
-        {
-            const uint32_t half = (dw[s] >> (16 * h)) & 0xFFFFu;
-            const uint2 e0 = lut[half & 255u], e1 = lut[half >> 8];
-            b[u][s] = v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
-        }
-    }
-
-    // train tile staging: thread tid expands dword (tid & 7) of row (tid >> 3) of the tile
-    const int tr = tid >> 3, tw = tid & 7;
     const int n_tiles = (n_from + 31) >> 5;
+
     if(n_tiles == 0)
     {
         // no train rows at all: every query gets "no neighbour"
@@ -241,107 +209,143 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
         return;
     }
-    // rows past the end re-read the last row (no branch); they are only ever used in the last tile, where
-    // their keys are masked
-    auto fetch = [&](int t) -> uint32_t { return from[(size_t)min(t * 32 + tr, n_from - 1) * 8 + tw]; };
-    uint32_t d_next;
-    auto stage = [&](int buf, uint32_t d) {
-        const uint2 e0 = lut[d & 255u], e1 = lut[(d >> 8) & 255u], e2 = lut[(d >> 16) & 255u], e3 = lut[d >> 24];
-        uint4* dst = reinterpret_cast<uint4*>(&tile[buf][tr * MM_TROW + tw * 32]);
-        dst[0] = make_uint4(e0.x, e0.y, e1.x, e1.y);
-        dst[1] = make_uint4(e2.x, e2.y, e3.x, e3.y);
+    {
+        uint32_t e = 0;
+#pragma unroll
+        for(int i = 0; i < 8; ++i)
+            e |= (((uint32_t)tid >> i) & 1u ? 0x2u : 0xAu) << (4 * i);
+        lut[tid] = e;
+    }
+    __syncthreads();
+    auto expand = [&](uint32_t d) -> uint4 { // 32 descriptor bits -> 32 FP4 values
+        return make_uint4(lut[d & 255u], lut[(d >> 8) & 255u], lut[(d >> 16) & 255u], lut[d >> 24]);
     };
 
-    uint32_t T[16]; // age of register i's train row inside its tile: 31 - row
-    v16i cinit, zero;
+    // B fragments: lane (r, h) holds bits [64 s + 32 h, +32) of query r for k-step s
+    v8i b[QT][4];
+#pragma unroll
+    for(int u = 0; u < QT; ++u)
+    {
+        const int q = q0 + (wave * QT + u) * 32 + r;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if(q < n_to)
+        {
+            const uint4* qp = reinterpret_cast<const uint4*>(to + (size_t)q * 32);
+            lo = qp[0];
+            hi = qp[1];
+        }
+        const uint32_t dw[4] = {h ? lo.y : lo.x, h ? lo.w : lo.z, h ? hi.y : hi.x, h ? hi.w : hi.z};
+#pragma unroll
+        for(int s = 0; s < 4; ++s)
+        {
+            const uint4 e = expand(dw[s]);
+            b[u][s] = v8i{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};
+        }
+    }
+
+    // train tile staging: thread tid expands dword (tid & 7) of row (tid >> 3) of the tile.  Rows past the
+    // end re-read the last row (no branch); they only ever land in the last tile, where their keys are masked.
+    const int tr = tid >> 3, tw = tid & 7;
+    auto fetch = [&](int t) -> uint32_t { return from[(size_t)min(t * 32 + tr, n_from - 1) * 8 + tw]; };
+    auto stage = [&](int buf, uint32_t d) {
+        *reinterpret_cast<uint4*>(&tile[buf][tr * MM_TROW + tw * 16]) = expand(d);
+    };
+    auto read_frags = [&](int buf, v8i (&af)[4]) {
+#pragma unroll
+        for(int s = 0; s < 4; ++s)
+        {
+            const uint4 e = *reinterpret_cast<const uint4*>(&tile[buf][r * MM_TROW + (2 * s + h) * 16]);
+            af[s] = v8i{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};
+        }
+    };
+
+    v16f cinit;
+    uint32_t zero[16];
 #pragma unroll
     for(int i = 0; i < 16; ++i)
     {
-        T[i] = 31u - (uint32_t)((i & 3) + 8 * (i >> 2) + 4 * h);
-        cinit[i] = 257;
-        zero[i] = 0;
+        cinit[i] = 257.f * MM_KEY_UNIT + (float)(31 - ((i & 3) + 8 * (i >> 2) + 4 * h));
+        zero[i] = 0u;
     }
     uint32_t best0[QT], best1[QT];
 #pragma unroll
     for(int u = 0; u < QT; ++u)
         best0[u] = best1[u] = 0u;
 
+    auto dots = [&](const v8i (&af)[4], int u, uint32_t (&key)[16]) {
+        v16f acc = cinit;
+#pragma unroll
+        for(int s = 0; s < 4; ++s)
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[s], b[u][s], acc, 4, 4, 0, 127, 0, 127 + 14);
+#pragma unroll
+        for(int i = 0; i < 16; ++i)
+            key[i] = __float_as_uint(acc[i]);
+    };
     // running top-2 of one query over the 16 train rows a lane holds of one tile
-    auto top2 = [&](const v16i& acc, uint32_t& b0, uint32_t& b1) {
-        b0 += 32u; // everything found so far is one tile older
-        b1 += 32u;
+    auto top2 = [&](const uint32_t (&key)[16], uint32_t& b0, uint32_t& b1) {
+        b0 = __float_as_uint(__uint_as_float(b0) + 32.f); // everything found so far is one tile older
+        b1 = __float_as_uint(__uint_as_float(b1) + 32.f);
 #pragma unroll
         for(int i = 0; i < 16; ++i)
         {
-            const uint32_t g = lshl_add((uint32_t)acc[i], 16, T[i]);
-            b1 = med3_u32(b0, b1, g); // b0 >= b1: the median is the new runner-up
-            b0 = max(b0, g);
+            // b0 >= b1: the median is the new runner-up.  The builtin, not inline asm: the compiler must see
+            // this read of an MFMA result to keep the MFMA -> VALU wait states.
+            b1 = __float_as_uint(
+                __builtin_amdgcn_fmed3f(__uint_as_float(b0), __uint_as_float(b1), __uint_as_float(key[i])));
+            b0 = max(b0, key[i]);
         }
-    };
-    // One tile step, software-pipelined by hand: the MFMAs of tile t run beside the top-2 VALU work of
-    // tile t-1 (independent registers), which the matrix pipe otherwise waits for (8 MFMAs = 256 cycles,
-    // top-2 of their 16 results = 50 VALU issues = 200 cycles).  Branch-free so it stays one block.
-    auto step = [&](int t, const v16i (&old_acc)[QT], v16i (&new_acc)[QT]) {
-        const int buf = t & 1;
-        stage(buf ^ 1, d_next);
-        d_next = fetch(t + 2);
-        v4i af[8];
-#pragma unroll
-        for(int s = 0; s < 8; ++s)
-            af[s] = *reinterpret_cast<const v4i*>(&tile[buf][r * MM_TROW + s * 32 + h * 16]);
-#pragma unroll
-        for(int u = 0; u < QT; ++u)
-        {
-            v16i acc = cinit;
-#pragma unroll
-            for(int s = 0; s < 8; ++s)
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[u][s], acc, 0, 0, 0);
-            new_acc[u] = acc;
-        }
-#pragma unroll
-        for(int u = 0; u < QT; ++u)
-            top2(old_acc[u], best0[u], best1[u]);
-        __syncthreads();
     };
 
-    v16i accP[QT], accQ[QT];
+    // Software pipeline, by hand: the MFMAs of one query tile run beside the top-2 VALU work of the previous
+    // one (different registers); the last query tile of a train tile is finished under the next train tile.
+    uint32_t keyA[16], keyB[16], pend[16];
 #pragma unroll
-    for(int u = 0; u < QT; ++u)
-        accP[u] = zero; // "tile -1": keys below 1 << 16 never beat a real neighbour
+    for(int i = 0; i < 16; ++i)
+        pend[i] = 0u; // "tile -1": keys below 2^14 never beat a real neighbour
+    uint32_t d_next;
     stage(0, fetch(0));
     d_next = fetch(1);
     __syncthreads();
-    int t = 0;
-    for(; t + 1 < n_tiles; t += 2)
+    const int n_full = n_tiles - 1; // the last tile (possibly partial) is peeled: its keys need masking
+    for(int t = 0; t < n_full; ++t)
     {
-        step(t, accP, accQ);
-        step(t + 1, accQ, accP);
-    }
-    if(t < n_tiles)
-    {
-        step(t, accP, accQ);
+        const int buf = t & 1;
+        stage(buf ^ 1, d_next);
+        d_next = fetch(t + 2);
+        v8i af[4];
+        read_frags(buf, af);
+        static_assert(QT == 2 || QT == 4, "pipeline below is written for 2 or 4 query tiles per wave");
+        dots(af, 0, keyA);
+        top2(pend, best0[QT - 1], best1[QT - 1]);
+        dots(af, 1, keyB);
+        top2(keyA, best0[0], best1[0]);
+        if(QT == 4)
+        {
+            dots(af, 2, keyA);
+            top2(keyB, best0[1], best1[1]);
+            dots(af, 3, keyB);
+            top2(keyA, best0[2], best1[2]);
+        }
 #pragma unroll
-        for(int u = 0; u < QT; ++u)
-            accP[u] = accQ[u];
+        for(int i = 0; i < 16; ++i)
+            pend[i] = keyB[i];
+        __syncthreads();
     }
-    // the last tile (possibly partial: rows past n_from are masked out here)
-    if(n_tiles > 0)
+    if(n_full > 0)
+        top2(pend, best0[QT - 1], best1[QT - 1]);
     {
-        const int base = (n_tiles - 1) * 32;
+        v8i af[4];
+        read_frags(n_full & 1, af);
+        const int base = n_full * 32;
 #pragma unroll
         for(int u = 0; u < QT; ++u)
         {
-            best0[u] += 32u;
-            best1[u] += 32u;
+            dots(af, u, keyA);
 #pragma unroll
             for(int i = 0; i < 16; ++i)
-            {
-                uint32_t g = lshl_add((uint32_t)accP[u][i], 16, T[i]);
-                if(base + (int)(31u - T[i]) >= n_from)
-                    g = 0u;
-                best1[u] = med3_u32(best0[u], best1[u], g);
-                best0[u] = max(best0[u], g);
-            }
+                if(base + (i & 3) + 8 * (i >> 2) + 4 * h >= n_from)
+                    keyA[i] = 0u;
+            top2(keyA, best0[u], best1[u]);
         }
     }
 
@@ -357,32 +361,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         {
             const size_t o = (size_t)pair * a.cap + q;
             const int last = 32 * n_tiles - 1;
-            a.idx0[o] = (m0 >> 16) ? last - (int)(m0 & 0xFFFFu) : -1;
-            a.idx1[o] = (m1 >> 16) ? last - (int)(m1 & 0xFFFFu) : -1;
-            a.dist0[o] = (m0 >> 16) ? (int32_t)((513u - (m0 >> 16)) >> 1) : INT_MAX;
-            a.dist1[o] = (m1 >> 16) ? (int32_t)((513u - (m1 >> 16)) >> 1) : INT_MAX;
+            const uint32_t k0 = (uint32_t)__uint_as_float(m0), k1 = (uint32_t)__uint_as_float(m1); // exact integers
+            a.idx0[o] = (k0 >> 14) ? last - (int)(k0 & 16383u) : -1;
+            a.idx1[o] = (k1 >> 14) ? last - (int)(k1 & 16383u) : -1;
+            a.dist0[o] = (k0 >> 14) ? (int32_t)((513u - (k0 >> 14)) >> 1) : INT_MAX;
+            a.dist1[o] = (k1 >> 14) ? (int32_t)((513u - (k1 >> 14)) >> 1) : INT_MAX;
         }
     }
 }
 
 template <int QT>
-static void launch_mfma(MatchArgs a, int n_pairs, hipStream_t s)
+static void launch_fp4(MatchArgs a, int n_pairs, hipStream_t s)
 {
     a.n_pairs = n_pairs;
     a.wg_per_pair = (a.cap + 128 * QT - 1) / (128 * QT);
     const unsigned grid = (unsigned)((n_pairs + 7) / 8) * 8u * (unsigned)a.wg_per_pair;
-    hipLaunchKernelGGL((k_match_knn2_mfma<QT>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_match_knn2_fp4<QT>), dim3(grid), dim3(256), 0, s, a);
 }
 
 void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
 {
-    static const int variant = getenv("MSLAM_MATCH_VARIANT") ? atoi(getenv("MSLAM_MATCH_VARIANT")) : 2;
-    if(variant == 1)
-        return launch_mfma<1>(a, n_pairs, s);
-    if(variant == 2)
-        return launch_mfma<2>(a, n_pairs, s);
-    // 8 waves x 1 query per lane, 8 rows per scalar-load batch: measured fastest of the variants tried
-    // (the loop is bound by integer VALU issue: 8 xor + 8 bcnt + 4 top-2 ops per pair).
+    // matrix-core kernel (4 query tiles per wave: 0.117 ms per 250 x 1900^2 pairs against 0.48 ms for the
+    // VALU kernel) whenever the train side fits its 14-bit age field; the VALU kernel otherwise
+    // (8 waves x 1 query per lane, 8 rows per scalar-load batch: the fastest of its variants).
+    const int max_train = a.from_cnt ? a.cap_from : a.n_from_fixed;
+    if(max_train <= MM_MAX_TRAIN)
+        return launch_fp4<4>(a, n_pairs, s);
     launch_variant<8, 1, 8>(a, n_pairs, s);
 }
 
