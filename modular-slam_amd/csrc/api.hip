@@ -380,7 +380,7 @@ static int create_impl(mslam_hip_ctx* c)
 
     {
         const char* e = getenv("MSLAM_HIP_STREAMS");
-        c->n_side = e ? std::max(1, std::min(atoi(e), 4)) : 3; // measured (batch 250): 1 / 2 / 3 / 4 chunks = 275 / 284 / 287 / 275 M kp/s
+        c->n_side = e ? std::max(1, std::min(atoi(e), 4)) : 2; // measured in one run (batch 250): 1 / 2 / 3 / 4 chunks = 366 / 375 / 369 / 361 M kp/s
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for(int k = 0; k < c->n_side; ++k)
         {
@@ -463,8 +463,9 @@ static int create_impl(mslam_hip_ctx* c)
     const size_t B = (size_t)p.max_batch, L = (size_t)p.n_levels, cap = (size_t)p.max_candidates;
     const size_t K = (size_t)p.max_keypoints;
     HIPCHK(c, dmalloc(c->d_stage, (size_t)p.width * p.height * 3));
-    HIPCHK(c, dmalloc(c->d_pyr, B * g.slab));
-    HIPCHK(c, dmalloc(c->d_blur, B * g.slab));
+    // + 64: the patch loads of k_describe may run a few bytes past the last row of the last frame
+    HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 64));
+    HIPCHK(c, dmalloc(c->d_blur, B * g.slab + 64));
     HIPCHK(c, dmalloc(c->d_cell_cnt, B * g.n_cells));
     HIPCHK(c, dmalloc(c->d_cell_kp, B * g.n_cells * (size_t)kCellCap));
     QuadArgs& q = c->quad;

@@ -113,6 +113,7 @@ struct DescArgs
     float* response;
     int32_t* count;
     uint32_t* flags;
+    int n_frames = 0; // filled in by the launcher
 };
 void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_frames, hipStream_t s);
 

@@ -75,7 +75,6 @@ __device__ __forceinline__ float util_sin(float v)
 constexpr int kPatchR = 19;               // sample radius of the rotated pattern (orb_patch_radius_)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 39
 constexpr int kPatchDw = 11;              // 44 aligned bytes per staged row cover the 39 needed ones
-constexpr int kGroup = 64;                // keypoints per workgroup pass: one lane each in the trig phase
 constexpr int kBlocksPerFrame = 32;
 
 // 64-lane integer sum with DPP adds (VALU only, no LDS crossbar); the total lands in lane 63
@@ -97,28 +96,39 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
     return v;
 }
 
-// A workgroup (4 waves) takes 64 keypoints at a time through three phases:
-//  A. moments, one wave per keypoint (16 each): the radius-15 disc is 31 rows x 8 dwords; lane t (+64k)
+// Every WAVE is an independent worker (no workgroup barriers): it takes kBatch keypoints at a time through
+//  0. one LANE per keypoint: which level, which candidate word (kept in that lane's registers and
+//     broadcast later with v_readlane);
+//  A. moments, the whole wave on one keypoint: the radius-15 disc is 31 rows x 8 dwords; lane t (+64k)
 //     owns dword (row t/8, column group t%8), loads it with one unaligned dword load and folds it into
 //     m10/m01 with two signed v_dot4 against per-lane weight bytes (u resp. v inside the disc, 0
 //     outside; host-built table).  Pixels are biased by -128 (xor 0x80) to fit i8; the bias cancels
 //     exactly because the disc is symmetric (sum of u = sum of v = 0).  Integer sums: order-free.
+//     The loads of the next two keypoints are issued before the current two are reduced.
 //  B. one LANE per keypoint: fastAtan2, the f64 degree->radian product, util::cos/sin and the scalar
 //     outputs (coordinates, octave, angle, response) — the wave-uniform float work of phase C is
 //     thereby done once per keypoint instead of once per lane.
-//  C. descriptors, one wave per keypoint: the 39x39 blurred patch is staged in LDS with coalesced
-//     aligned dword loads, the 512 rotated sample points are LDS byte gathers, and four ballots are
-//     the 32 descriptor bytes.
-// Everything a wave needs about "its" keypoint is wave-uniform and kept in SGPRs (readfirstlane).
+//  C. descriptors, the whole wave on one keypoint: the 39x39 blurred patch is staged in LDS with
+//     coalesced aligned dword loads, the 512 rotated sample points are LDS byte gathers, and four
+//     ballots are the 32 descriptor bytes.  The global loads of the next two patches are in flight
+//     (in registers) while the current two are sampled.
+// Everything a wave needs about "its" keypoint is wave-uniform and kept in SGPRs (readlane).
+constexpr int kBatch = 16;
+constexpr int kWavesPerFrame = kBlocksPerFrame * 4;
+
 __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
 {
     __shared__ uint32_t patch[4][2][kPatchRows * kPatchDw];
-    __shared__ int s_m10[kGroup], s_m01[kGroup];
-    __shared__ uint32_t s_kp[kGroup];   // packed candidate word
-    __shared__ int s_level[kGroup];
-    __shared__ float s_ca[kGroup], s_sa[kGroup];
 
-    const size_t frame = blockIdx.y + g.frame0;
+    // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, so all kBlocksPerFrame
+    // workgroups of a frame are given ids with the same (id & 7): the two level slabs of a frame (1.9 MB)
+    // are then gathered through ONE 4 MB L2 instead of being pulled into all eight.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int f_local = (slot / kBlocksPerFrame) * 8 + xcd;
+    if(f_local >= a.n_frames)
+        return;
+    const int bx = slot % kBlocksPerFrame;
+    const size_t frame = (size_t)f_local + g.frame0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     int total = 0;
     for(int l = 0; l < g.n_levels; ++l)
         total += (int)sel_cnt[l];
-    if(blockIdx.x == 0 && threadIdx.x == 0)
+    if(bx == 0 && threadIdx.x == 0)
     {
         a.count[frame] = min(total, a.max_kp);
         if(total > a.max_kp)
@@ -135,46 +145,54 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     }
     const int n_kp = min(total, a.max_kp);
 
-    // per-lane disc weights (constant across keypoints)
+    // per-lane constants: disc weights and this lane's four sampling pairs
     uint32_t wu[4], wv[4];
+    float4 pat[4];
 #pragma unroll
     for(int k = 0; k < 4; ++k)
     {
         wu[k] = a.orient_w[lane + 64 * k];
         wv[k] = a.orient_w[256 + lane + 64 * k];
+        pat[k] = reinterpret_cast<const float4*>(c_pattern_f)[lane + 64 * k];
     }
     const uint8_t* pyr = a.pyr + frame * g.slab;
     const uint8_t* blur = a.blur + frame * g.slab;
 
-    for(int base = blockIdx.x * kGroup; base < n_kp; base += gridDim.x * kGroup)
+    for(int base = (bx * 4 + wave) * kBatch; base < n_kp; base += kWavesPerFrame * kBatch)
     {
-        const int n_here = min(kGroup, n_kp - base);
+        const int n_here = min(kBatch, n_kp - base); // wave-uniform
 
         // ---- 0. one lane per keypoint: which level, which candidate word
-        if(threadIdx.x < n_here)
+        uint32_t my_kp = 0;
+        int my_level = 0;
+        if(lane < n_here)
         {
-            int local = base + threadIdx.x, level = 0;
+            int local = base + lane;
             for(int l = 0; l < g.n_levels; ++l)
             {
                 const int c = (int)sel_cnt[l];
                 if(local < c)
                 {
-                    level = l;
+                    my_level = l;
                     break;
                 }
                 local -= c;
             }
-            s_kp[threadIdx.x] = a.sel[(frame * g.n_levels + level) * (size_t)a.cand_cap + local];
-            s_level[threadIdx.x] = level;
+            my_kp = a.sel[(frame * g.n_levels + my_level) * (size_t)a.cand_cap + local];
         }
-        __syncthreads();
+        auto kp_of = [&](int k, int& px, int& py) -> const LevelGeom& {
+            const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)my_kp, k);
+            px = kp_x(p) + kBorder; // :966-967
+            py = kp_y(p) + kBorder;
+            return g.lv[__builtin_amdgcn_readlane(my_level, k)];
+        };
 
-        // ---- A. moments; two keypoints per wave are in flight at a time
+        // ---- A. moments
+        int my_m10 = 0, my_m01 = 0;
         {
             auto fetch = [&](int k, uint32_t (&dw)[4]) {
-                const uint32_t p = __builtin_amdgcn_readfirstlane(s_kp[k]);
-                const LevelGeom& lv = g.lv[__builtin_amdgcn_readfirstlane(s_level[k])];
-                const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder; // :966-967
+                int px, py;
+                const LevelGeom& lv = kp_of(k, px, py);
                 const uint8_t* raw = pyr + lv.offset + (py - 15) * lv.pitch + (px - 15);
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
@@ -192,57 +210,56 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     m10 = __builtin_amdgcn_sdot4((int)x, (int)wu[q], m10, false);
                     m01 = __builtin_amdgcn_sdot4((int)x, (int)wv[q], m01, false);
                 }
-                m10 = wave_sum_dpp(m10);
-                m01 = wave_sum_dpp(m01);
-                if(lane == 0)
-                {
-                    s_m10[k] = m10;
-                    s_m01[k] = m01;
-                }
+                { const int t10 = wave_sum_dpp(m10); my_m10 = lane == k ? t10 : my_m10; }
+                { const int t01 = wave_sum_dpp(m01); my_m01 = lane == k ? t01 : my_m01; }
             };
-            for(int k = wave; k < n_here; k += 8)
+            uint32_t c0[4], c1[4], n0[4], n1[4];
+            fetch(0, c0);
+            if(1 < n_here)
+                fetch(1, c1);
+            for(int k = 0; k < n_here; k += 2)
             {
-                uint32_t d0[4], d1[4];
-                fetch(k, d0);
-                if(k + 4 < n_here)
-                    fetch(k + 4, d1);
-                reduce(k, d0);
-                if(k + 4 < n_here)
-                    reduce(k + 4, d1);
+                if(k + 2 < n_here)
+                    fetch(k + 2, n0);
+                if(k + 3 < n_here)
+                    fetch(k + 3, n1);
+                reduce(k, c0);
+                if(k + 1 < n_here)
+                    reduce(k + 1, c1);
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    c0[q] = n0[q];
+                    c1[q] = n1[q];
+                }
             }
         }
-        __syncthreads();
 
         // ---- B. one lane per keypoint: angle, cos/sin, scalar outputs
-        if(threadIdx.x < n_here)
+        float my_ca = 0.f, my_sa = 0.f;
+        if(lane < n_here)
         {
-            const int k = threadIdx.x;
-            const float angle = fast_atan2_deg((float)s_m01[k], (float)s_m10[k]);
+            const float angle = fast_atan2_deg((float)my_m01, (float)my_m10);
             const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0); // :574
-            s_ca[k] = util_cos(rad);
-            s_sa[k] = util_sin(rad);
-            const uint32_t p = s_kp[k];
-            const int level = s_level[k];
-            const float scale = g.lv[level].scale;
-            const float fx = (float)(kp_x(p) + kBorder), fy = (float)(kp_y(p) + kBorder);
-            const size_t o = frame * (size_t)a.max_kp + base + k;
+            my_ca = util_cos(rad);
+            my_sa = util_sin(rad);
+            const float scale = g.lv[my_level].scale;
+            const float fx = (float)(kp_x(my_kp) + kBorder), fy = (float)(kp_y(my_kp) + kBorder);
+            const size_t o = frame * (size_t)a.max_kp + base + lane;
             // correct_keypoint_scale (:1166-1179): float multiply, skipped for level 0
-            a.xy[2 * o] = level == 0 ? fx : __fmul_rn(fx, scale);
-            a.xy[2 * o + 1] = level == 0 ? fy : __fmul_rn(fy, scale);
-            a.octave[o] = level;
+            a.xy[2 * o] = my_level == 0 ? fx : __fmul_rn(fx, scale);
+            a.xy[2 * o + 1] = my_level == 0 ? fy : __fmul_rn(fy, scale);
+            a.octave[o] = my_level;
             a.angle[o] = angle;
-            a.response[o] = (float)kp_score(p);
+            a.response[o] = (float)kp_score(my_kp);
         }
-        __syncthreads();
 
-        // ---- C. descriptors; two keypoints per wave are in flight at a time
+        // ---- C. descriptors
         {
-            auto stage = [&](int k, int buf, int& sh_out) {
-                const uint32_t p = __builtin_amdgcn_readfirstlane(s_kp[k]);
-                const LevelGeom& lv = g.lv[__builtin_amdgcn_readfirstlane(s_level[k])];
-                const int px = kp_x(p) + kBorder, py = kp_y(p) + kBorder;
+            auto load_patch = [&](int k, uint32_t (&r)[7]) {
+                int px, py;
+                const LevelGeom& lv = kp_of(k, px, py);
                 const int bx0 = px - kPatchR, sh = bx0 & 3;
-                sh_out = sh;
                 const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * lv.pitch + (bx0 - sh);
                 const uint32_t* bsrc32 = reinterpret_cast<const uint32_t*>(bsrc); // wave-uniform base, 32-bit lane offsets
                 const uint32_t pitch = (uint32_t)lv.pitch;
@@ -250,23 +267,36 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 for(int q = 0; q < 7; ++q)
                 {
                     const uint32_t t = (uint32_t)lane + 64u * q;
+                    r[q] = 0;
                     if(t < (uint32_t)(kPatchRows * kPatchDw))
                     {
-                        const uint32_t r = (t * 5958u) >> 16; // t / 11 for t < 429
-                        const uint32_t c = t - r * kPatchDw;
-                        patch[wave][buf][t] = bsrc32[(__umul24(r, pitch) >> 2) + c];
+                        const uint32_t row = (t * 5958u) >> 16; // t / 11 for t < 429
+                        const uint32_t col = t - row * kPatchDw;
+                        r[q] = bsrc32[(__umul24(row, pitch) >> 2) + col];
                     }
                 }
             };
-            auto describe = [&](int k, int buf, int sh) {
-                const float ca = s_ca[k], sa = s_sa[k];
+            auto store_patch = [&](int buf, const uint32_t (&r)[7]) {
+#pragma unroll
+                for(int q = 0; q < 7; ++q)
+                {
+                    const uint32_t t = (uint32_t)lane + 64u * q;
+                    if(t < (uint32_t)(kPatchRows * kPatchDw))
+                        patch[wave][buf][t] = r[q];
+                }
+            };
+            auto describe = [&](int k, int buf) {
+                const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ca), k));
+                const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sa), k));
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)my_kp, k);
+                const int sh = (kp_x(p) + kBorder - kPatchR) & 3;
                 const uint8_t* bc =
                     reinterpret_cast<const uint8_t*>(patch[wave][buf]) + kPatchR * (kPatchDw * 4) + kPatchR + sh; // centre
                 unsigned long long bits[4];
 #pragma unroll
                 for(int t = 0; t < 4; ++t)
                 {
-                    const float4 q = reinterpret_cast<const float4*>(c_pattern_f)[lane + 64 * t];
+                    const float4 q = pat[t];
                     // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
                     const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(q.x, sa), __fmul_rn(q.y, ca)));
                     const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(q.x, ca), __fmul_rn(q.y, sa)));
@@ -285,30 +315,37 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k) * 32)[lane] = w;
                 }
             };
-            for(int k = wave; k < n_here; k += 8)
+            uint32_t r0[7], r1[7];
+            load_patch(0, r0);
+            if(1 < n_here)
+                load_patch(1, r1);
+            for(int k = 0; k < n_here; k += 2)
             {
-                int sh0 = 0, sh1 = 0;
-                const bool two = k + 4 < n_here;
                 __builtin_amdgcn_wave_barrier(); // the previous pair's gathers are done before the patches are overwritten
-                stage(k, 0, sh0);
-                if(two)
-                    stage(k + 4, 1, sh1);
+                store_patch(0, r0);
+                if(k + 1 < n_here)
+                    store_patch(1, r1);
+                if(k + 2 < n_here)
+                    load_patch(k + 2, r0);
+                if(k + 3 < n_here)
+                    load_patch(k + 3, r1);
                 __builtin_amdgcn_wave_barrier();
-                describe(k, 0, sh0);
-                if(two)
-                    describe(k + 4, 1, sh1);
+                describe(k, 0);
+                if(k + 1 < n_here)
+                    describe(k + 1, 1);
             }
         }
-        __syncthreads(); // LDS keypoint slots are reused by the next group
     }
 }
 
 void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_frames, hipStream_t s)
 {
-    dim3 grid(kBlocksPerFrame, n_frames);
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, s, gg, a);
+    DescArgs aa = a;
+    aa.n_frames = n_frames;
+    const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * kBlocksPerFrame;
+    hipLaunchKernelGGL(k_describe, dim3(grid), dim3(256), 0, s, gg, aa);
 }
 
 } // namespace mslam

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Per-kernel medians of every counter in a rocprofv3 --pmc counter_collection.csv.  usage: summarize_sq.py <csv> [out.json]"""
+import collections, csv, json, sys
+d = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: sorted(v)[len(v) // 2] for c, v in cs.items()} for k, cs in d.items()}
+if len(sys.argv) > 2:
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+for k, cs in out.items():
+    print(k[-40:])
+    for c, v in sorted(cs.items()):
+        print("    %-28s %16.0f" % (c, v))
