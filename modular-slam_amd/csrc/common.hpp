@@ -70,8 +70,21 @@ enum : uint32_t
 void launch_gray(const uint8_t* d_bgr, uint8_t* d_pyr, const Geometry& g, int frame0, int n_frames, hipStream_t s);
 void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,
                    const int32_t* d_yofs, const uint32_t* d_ycoef, int frame0, int n_frames, hipStream_t s);
-void launch_resize_quad(uint8_t* d_pyr, const Geometry& g, int level, const uint32_t* d_qbase, const uint4* d_qw,
-                        const int32_t* d_yofs, const uint32_t* d_ycoef, int frame0, int n_frames, hipStream_t s);
+struct ResizeColArgs
+{
+    uint8_t* pyr;
+    unsigned slab;
+    int src_off, sh, spitch, dst_off, dw, dh, dpitch;
+    const uint4* qt;       // [quads][3]: {byte offset, upper flags, sel0, sel1} {sel2, sel3, coef0, coef1} {coef2, coef3, -, -}
+    const int32_t* yofs;   // [dh]
+    const uint32_t* ycoef; // [dh] b0 | b1 << 16
+    int frame0, n_frames;
+    int quads;
+    float inv_quads;
+    int R;         // destination rows per lane
+    int need_mask; // bit k: pixel k of some quad takes its pair from dwords (1,2)
+};
+void launch_resize_col(const ResizeColArgs& a, hipStream_t s);
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
                  uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s);
 struct QuadArgs

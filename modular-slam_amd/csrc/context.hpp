@@ -54,9 +54,9 @@ struct mslam_hip_ctx
     int32_t* d_rs_ofs = nullptr;   // resize offsets, all levels
     uint32_t* d_rs_coef = nullptr; // resize coefficients, all levels
     std::vector<size_t> rs_x, rs_y; // per-level start index into d_rs_*
-    uint32_t* d_rs_qbase = nullptr; // quad tables (k_resize_quad), all levels
-    uint4* d_rs_qw = nullptr;
-    std::vector<size_t> rs_q;       // per-level start index into the quad tables; SIZE_MAX = use the generic kernel
+    uint4* d_rs_qt = nullptr;       // quad tables (k_resize_col), all levels, 3 x uint4 per quad
+    std::vector<size_t> rs_q;       // per-level start (in quads) into the quad tables; SIZE_MAX = use the generic kernel
+    std::vector<int> rs_need;       // per level: which pixel positions of a quad ever use the upper dword pair
     int32_t* d_ratio_thr = nullptr; // [257]
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
     double ratio_cached = -1.0;

@@ -111,75 +111,134 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
     *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + (qx << 2)) = out;
 }
 
-// Quad form of the same interpolation: the 4 destination pixels of a lane draw on at most 12
-// consecutive source bytes per row, so the lane loads three ALIGNED dwords per source row.  The host
-// table holds, per destination pixel, which dword pair contains its two source bytes and at which byte
-// offset, so ONE v_perm_b32 per row cuts (S[sx], S[sx+1]) out as a u16 pair and the horizontal blend
-// is one v_dot2_u32_u16.  Table word: i0 (3 bits: byte index of S[sx] inside the chosen pair) |
-// upper-pair flag (bit 3) | a0 << 4 | a1 << 16.
-__global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, unsigned slab, int src_off, int sh,
-                                                     int spitch, int dst_off, int dw, int dh, int dpitch,
-                                                     const uint32_t* __restrict__ qbase, const uint4* __restrict__ qw,
-                                                     const int32_t* __restrict__ yofs, const uint32_t* __restrict__ ycoef,
-                                                     int frame0)
+// Column form of the same interpolation.  One lane owns one destination QUAD COLUMN (4 pixels wide) of one
+// frame and walks down R destination rows; lanes are flattened over (frame, quad) so that narrow levels keep
+// all 64 lanes busy, and every lane of a wave is on the same rows, so the row logic is scalar.
+//   horizontal (HResizeLinear): the 4 pixels draw on at most 12 consecutive source bytes, loaded as three
+//     ALIGNED dwords; the host table (3 x uint4 per quad: byte offset of the window, per-pixel v_perm selector
+//     cutting (S[sx], S[sx+1]) out as a u16 pair, per-pixel (a0, a1) coefficient pair, flags: pair in dwords
+//     (1,2) instead of (0,1)) makes it one v_perm_b32 + one v_dot2_u32_u16 per pixel.  The interpolated values
+//     (>> 4) of the last two source rows stay in registers: at scale 1.2 a destination row re-uses the lower
+//     source row of the previous one 4 times out of 5, so 1.2 source rows are interpolated per row, not 2;
+//   vertical (VResizeLinear): two 24-bit multiplies per pixel, one dword store per quad.
+__global__ __launch_bounds__(256) void k_resize_col(ResizeColArgs a)
 {
-    const int qx = blockIdx.x * 64 + threadIdx.x;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    if(dy >= dh || (qx << 2) >= dw)
-        return;
-    const size_t frame = blockIdx.z + frame0;
-    const uint8_t* src = pyr + frame * slab + src_off;
-    uint8_t* dst = pyr + frame * slab + dst_off;
-
-    int sy0 = yofs[dy], sy1 = sy0 + 1;
-    sy0 = max(0, min(sy0, sh - 1)); // resizeGeneric_Invoker clips the row index, not the weight
-    sy1 = max(0, min(sy1, sh - 1));
-    const uint32_t yc = ycoef[dy];
-    const uint32_t b0 = yc & 0xFFFF, b1 = yc >> 16;
-    const uint32_t base = qbase[qx];
-    const uint4 w4 = qw[qx];
-    const uint32_t* r0p = reinterpret_cast<const uint32_t*>(src + sy0 * spitch + base);
-    const uint32_t* r1p = reinterpret_cast<const uint32_t*>(src + sy1 * spitch + base);
-    const uint32_t a0 = r0p[0], a1 = r0p[1], a2 = r0p[2];
-    const uint32_t c0 = r1p[0], c1 = r1p[1], c2 = r1p[2];
-    const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+    // the block's row table lives in lane registers (lane i: destination row R0 + i, R <= 64) and is read with
+    // v_readlane: wave-uniform values without a memory access inside the loop.  Loaded by ALL lanes, before the
+    // tail lanes leave: v_readlane also reads lanes that have exited since.
+    const int R0 = blockIdx.y * a.R, r_end = min(R0 + a.R, a.dh);
+    const int lane = threadIdx.x & 63;
+    const int my_y0 = a.yofs[min(R0 + lane, a.dh - 1)];
+    const uint32_t my_yc = a.ycoef[min(R0 + lane, a.dh - 1)];
+    // resizeGeneric_Invoker clips the row index, not the weight
+    const int s_lo = max(0, min(__builtin_amdgcn_readlane(my_y0, 0), a.sh - 1));
+    const int s_hi = max(0, min(__builtin_amdgcn_readlane(my_y0, r_end - 1 - R0) + 1, a.sh - 1));
+    // tail lanes stay alive on a clamped item (v_readlane must be able to read every lane's row table); only
+    // their stores are masked
+    const int n_items = a.n_frames * a.quads;
+    const bool live = (int)(blockIdx.x * 256 + threadIdx.x) < n_items;
+    const int idx = min((int)(blockIdx.x * 256 + threadIdx.x), n_items - 1);
+    const int f = (int)(((float)idx + 0.5f) * a.inv_quads); // idx / quads, exact: see launch_resize_col
+    const int qx = idx - f * a.quads;
+    const size_t frame = (size_t)f + a.frame0;
+    const uint4 t0 = a.qt[3 * qx], t1 = a.qt[3 * qx + 1], t2 = a.qt[3 * qx + 2];
+    const uint8_t* src = a.pyr + frame * a.slab + a.src_off + t0.x;
+    uint8_t* dst = a.pyr + frame * a.slab + a.dst_off + (qx << 2);
+    const uint32_t sel[4] = {t0.z, t0.w, t1.x, t1.y}, coef[4] = {t1.z, t1.w, t2.x, t2.y};
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    uint32_t out = 0;
-#pragma unroll
-    for(int k = 0; k < 4; ++k)
+
+    struct Raw
     {
-        const uint32_t w = ws[k];
-        // selector bytes [i0, zero, i0+1, zero]: the pair lands as two u16 lanes
-        const uint32_t sel = 0x0c010c00u + (w & 7u) * 0x00010001u;
-        const bool upper = (w & 8u) != 0;
-        const uint32_t p0 = __builtin_amdgcn_perm(upper ? a2 : a1, upper ? a1 : a0, sel);
-        const uint32_t p1 = __builtin_amdgcn_perm(upper ? c2 : c1, upper ? c1 : c0, sel);
-        const uint32_t coef = ((w >> 4) & 0xFFF) | (w & 0xFFFF0000u); // (a0, a1) as a u16 pair
-        u16x2 cv, v0, v1;
-        cv.x = (unsigned short)(coef & 0xFFFF);
-        cv.y = (unsigned short)(coef >> 16);
-        v0.x = (unsigned short)(p0 & 0xFFFF);
-        v0.y = (unsigned short)(p0 >> 16);
-        v1.x = (unsigned short)(p1 & 0xFFFF);
-        v1.y = (unsigned short)(p1 >> 16);
-        const uint32_t r0 = __builtin_amdgcn_udot2(v0, cv, 0u, false);
-        const uint32_t r1 = __builtin_amdgcn_udot2(v1, cv, 0u, false);
-        // both factors are below 2^24 (weights <= 2048, r >> 4 <= 32640): 24-bit multiplies are full rate
-        const uint32_t v = ((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2) >> 2;
-        out |= v << (8 * k); // v <= 255
+        uint32_t d0, d1, d2;
+    };
+    struct Row
+    {
+        uint32_t h[4];
+    };
+    auto load = [&](int sy) {
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(src + (size_t)sy * a.spitch);
+        return Raw{rp[0], rp[1], rp[2]};
+    };
+    auto hinterp = [&](const Raw& w) {
+        Row r;
+#pragma unroll
+        for(int k = 0; k < 4; ++k)
+        {
+            uint32_t lo = w.d0, hi = w.d1;
+            if(a.need_mask & (1 << k)) // wave-uniform: this pixel position uses the upper pair somewhere on the level
+            {
+                const bool up = (t0.y >> k) & 1u;
+                lo = up ? w.d1 : w.d0;
+                hi = up ? w.d2 : w.d1;
+            }
+            const uint32_t pr = __builtin_amdgcn_perm(hi, lo, sel[k]);
+            u16x2 pv, cv;
+            pv.x = (unsigned short)(pr & 0xFFFF);
+            pv.y = (unsigned short)(pr >> 16);
+            cv.x = (unsigned short)(coef[k] & 0xFFFF);
+            cv.y = (unsigned short)(coef[k] >> 16);
+            r.h[k] = __builtin_amdgcn_udot2(pv, cv, 0u, false) >> 4;
+        }
+        return r;
+    };
+
+    // The block's destination rows draw on the contiguous source rows s_lo .. s_hi.  They are streamed
+    // through a 4-deep register ring (loads issued 4 rows ahead); after source row s is interpolated, every
+    // destination row whose lower source row is s is complete and is blended and stored.
+    constexpr int PF = 4;
+    Raw ring[PF];
+#pragma unroll
+    for(int i = 0; i < PF; ++i)
+        ring[i] = load(min(s_lo + i, s_hi));
+    int dy = R0;
+    Row h_prev{}, h_cur{};
+    auto consume = [&](int s, const Raw& w) {
+        h_prev = h_cur;
+        h_cur = hinterp(w);
+        // destination rows complete at source row s: sy1 == s (or both clipped to s)
+        while(dy < r_end)
+        {
+            const int y0 = __builtin_amdgcn_readlane(my_y0, dy - R0);
+            const int sy0 = max(0, min(y0, a.sh - 1)), sy1 = max(0, min(y0 + 1, a.sh - 1));
+            if(sy1 != s)
+                break;
+            const uint32_t yc = (uint32_t)__builtin_amdgcn_readlane((int)my_yc, dy - R0);
+            const uint32_t b0 = yc & 0xFFFF, b1 = yc >> 16;
+            const Row& h0 = sy0 == s ? h_cur : h_prev;
+            uint32_t out = 0;
+#pragma unroll
+            for(int k = 0; k < 4; ++k)
+            {
+                // both factors are below 2^24 (weights <= 2048, h <= 32640): 24-bit multiplies are full rate
+                const uint32_t v = ((__umul24(b0, h0.h[k]) >> 16) + (__umul24(b1, h_cur.h[k]) >> 16) + 2) >> 2; // <= 255
+                out |= v << (8 * k);
+            }
+            if(live)
+                *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch) = out;
+            ++dy;
+        }
+    };
+    for(int s = s_lo; s <= s_hi; s += PF)
+    {
+#pragma unroll
+        for(int i = 0; i < PF; ++i)
+        {
+            if(s + i <= s_hi)
+            {
+                const Raw w = ring[i];
+                ring[i] = load(min(s + i + PF, s_hi));
+                consume(s + i, w);
+            }
+        }
     }
-    *reinterpret_cast<uint32_t*>(dst + dy * dpitch + (qx << 2)) = out;
 }
 
-void launch_resize_quad(uint8_t* d_pyr, const Geometry& g, int level, const uint32_t* d_qbase, const uint4* d_qw,
-                        const int32_t* d_yofs, const uint32_t* d_ycoef, int frame0, int n_frames, hipStream_t s)
+void launch_resize_col(const ResizeColArgs& args, hipStream_t s)
 {
-    const LevelGeom& src = g.lv[level - 1];
-    const LevelGeom& dst = g.lv[level];
-    const int quads = (dst.w + 3) / 4;
-    dim3 grid((quads + 63) / 64, (dst.h + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_resize_quad, grid, dim3(64, 4), 0, s, d_pyr, g.slab, src.offset, src.h, src.pitch, dst.offset,
-                       dst.w, dst.h, dst.pitch, d_qbase, d_qw, d_yofs, d_ycoef, frame0);
+    // the float reciprocal reproduces idx / quads exactly: (idx + 0.5) / quads is at least 0.5 / quads away from
+    // an integer, far more than the rounding error for idx < 2^22 (api.hip checks frames x quads)
+    dim3 grid((args.n_frames * args.quads + 255) / 256, (args.dh + args.R - 1) / args.R);
+    hipLaunchKernelGGL(k_resize_col, grid, dim3(256), 0, s, args);
 }
 
 void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,
