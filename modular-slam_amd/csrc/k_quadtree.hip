@@ -378,7 +378,10 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
     static_assert(sizeof(l_nodes_b) >= (kMaxCellsPerLevel + 1) * sizeof(uint32_t), "cell offsets must fit");
     uint32_t* cell_off = reinterpret_cast<uint32_t*>(l_nodes_b);
 
-    const int level = blockIdx.x;
+    // Workgroups go to the 8 XCDs round-robin by linear id = frame * n_levels + blockIdx.x.  With the usual 8
+    // levels a plain level = blockIdx.x would give XCD 0 every level-0 workgroup (the heaviest) and XCD 7 every
+    // level-7 one; rotating the level by the frame index gives every XCD the same mix.
+    const int level = (int)((blockIdx.x + blockIdx.y) % (unsigned)g.n_levels);
     const size_t frame = blockIdx.y + g.frame0;
     const LevelGeom& lv = g.lv[level];
     const int tid = threadIdx.x;
