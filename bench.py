@@ -38,19 +38,22 @@ STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "mslam::k_resize_col", "fast
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact"}
 
 
-def pmc_traffic(stage, launches, frames_per_launch):
+def pmc_traffic(stage, kernels_per_launch, frames_per_launch):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced
     streaming reads — MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known
-    92.16 MB input confirms: it reads 45.0 MB raw).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write_per_launch.json")
+    input confirms: 125 frames x 921 600 B = 115.2 MB, FETCH_SIZE reads 57.6 MB).  None when no profile
+    is committed.  `kernels_per_launch`: the resize stage is 7 kernels (one per level) timed as one."""
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_fetch_write_per_launch.json")
     try:
         j = json.load(open(path))
-        d = j[STAGE_KERNEL[stage]]
-        scale = frames_per_launch / float(j["_meta"]["frames_per_launch"])  # traffic is linear in the batch size
+        k = STAGE_KERNEL[stage]
+        d = j[k]
+        fpl = j["_meta"]["frames_per_launch"]
+        scale = frames_per_launch / float(fpl.get(k, fpl["default"]))  # traffic is linear in the batch size
     except (OSError, KeyError, ValueError):
         return None
-    return int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024 * scale)
+    return int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024 * scale * kernels_per_launch)
 
 
 def parse():
@@ -68,6 +71,8 @@ def parse():
     ap.add_argument("--voc-levels", type=int, default=6, help="vocabulary depth L (k=10): 6 -> 1e6 words")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU run) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serialized", action="store_true",
+                    help="also report every stage timed alone (all work on one stream), after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=500, help="frames of the stream timed on the CPU oracle")
     return ap.parse_args()
 
@@ -164,34 +169,40 @@ def main():
             if world > 1:
                 cross.step_gpu(ctx)
 
-    for i in range(a.warmup):
+    # warm-up; the first pass over each distinct batch also counts its keypoints (the unit of the metric) and
+    # FAST candidates, so that no extra launches are needed after the timed region
+    counts_per_batch, cand_per_batch = {}, {}
+
+    def count_batch(b):
+        ctx.sync()
+        v = ctx.batch_view()  # the output set alternates between batches: fetch the view after every detect
+        counts_per_batch[b] = int(pkg.read_device(ctx, v.count, (B,), np.int32).sum())
+        cand_per_batch[b] = sum(len(ctx.debug_keypoints(pkg.DBG_CANDIDATES, 0, l)) for l in range(8)) * B
+
+    for i in range(max(a.warmup, n_batches)):
         step(i)
+        if i % n_batches not in counts_per_batch:
+            count_batch(i % n_batches)
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ctx.set_profiling(2)  # HIP events around the matcher kernel, in place on its own stream, during the timed steps
+    w_eff_pre = max(a.warmup, n_batches)
+    ctx.set_profiling(2)  # HIP events around every stage, in place on the stream it is launched on, during the timed steps
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(a.warmup + i)
+        step(w_eff_pre + i)
     ctx.sync()  # also surfaces capacity overflows loudly
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    match_ms_timed = [ms for _, ms in ctx.stage_times()]  # one entry per timed step
+    timed = ctx.stage_times(cap=4096)  # (stage, ms) of every launch of the timed steps
     ctx.set_profiling(0)
 
     # units processed: keypoints extracted (and matched against the previous frame) in the timed steps
-    counts_per_batch = []
-    cand_per_batch = []
-    for b in range(n_batches):  # untimed: count keypoints of each distinct batch once
-        ctx.detect_batch_dev(d_frames.data_ptr() + b * B * frame_bytes, B)
-        ctx.sync()
-        v = ctx.batch_view()  # the output set alternates between batches: fetch the view after every detect
-        counts_per_batch.append(int(pkg.read_device(ctx, v.count, (B,), np.int32).sum()))
-        cand_per_batch.append(sum(len(ctx.debug_keypoints(pkg.DBG_CANDIDATES, 0, l)) for l in range(8)) * B)
-    n_kp = sum(counts_per_batch[(a.warmup + i) % n_batches] for i in range(a.steps))
+    w_eff = max(a.warmup, n_batches)
+    n_kp = sum(counts_per_batch[(w_eff + i) % n_batches] for i in range(a.steps))
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     kp_sum = torch.tensor([float(n_kp)], dtype=torch.float64, device=red_dev)
@@ -202,38 +213,47 @@ def main():
 
     out = None
     if rank == 0:
-        # per-kernel timing with HIP events on the context's stream (outside the timed region)
-        ctx.set_profiling(True)
-        acc = {}
-        reps = 5
-        for i in range(reps):
-            step(i)
-            for name, ms in ctx.stage_times():
-                acc[name] = acc.get(name, 0.0) + ms / reps
-        ctx.set_profiling(False)
+        # per-stage launch durations measured inside the timed region (HIP events on the launching stream)
+        tot, cnt = {}, {}
+        for name, ms in timed:
+            tot[name] = tot.get(name, 0.0) + ms
+            cnt[name] = cnt.get(name, 0) + 1
+        avg = {k: tot[k] / cnt[k] for k in tot}                    # ms per launch
+        per_step = {k: cnt[k] / float(a.steps) for k in tot}       # launches per step (detector: one per chunk)
+        acc = {k: tot[k] / a.steps for k in tot}                   # ms per step, summed over the step's launches
         kp_b, cand_b = counts_per_batch[0], cand_per_batch[0]
-        sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)
-        serialized = dict(acc)
-        if match_ms_timed:
-            acc["match_knn2"] = float(np.mean(match_ms_timed))  # measured over the timed region itself
+        sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)  # per step (B frames)
         dom = max(acc, key=acc.get)
-        launches = 7 if dom == "resize" else 1
-        achieved = sb[dom] / (acc[dom] * 1e-3) / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, launches, B),
-                    "launches_per_step": launches, "avg_ms": round(acc[dom], 4),
-                    "algorithmic_bytes_per_launch": sb[dom] // launches,
-                    "timing": "match_knn2: HIP events on its stream inside the timed region (%d launches); other stages: "
-                              "HIP events in a serialised pass after it" % len(match_ms_timed),
-                    "stages_ms": {k: round(x, 4) for k, x in acc.items()},
-                    "stages_ms_serialized": {k: round(x, 4) for k, x in serialized.items()},
-                    "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0}}
+        fpl = B / per_step[dom]                                    # frames per launch of the dominant stage
+        bytes_per_launch = sb[dom] / per_step[dom]
+        achieved = bytes_per_launch / (avg[dom] * 1e-3) / 1e9
+        roofline = {"kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic(dom, 7 if dom == "resize" else 1, fpl),
+                    "launches_per_step": per_step[dom], "frames_per_launch": fpl, "avg_ms": round(avg[dom], 4),
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "timing": "HIP events on the launching stream around every stage launch of the %d timed steps "
+                              "(%d launches of the dominant stage); the resize entry spans its 7 per-level kernels" % (
+                                  a.steps, cnt[dom]),
+                    "stages_ms_per_launch": {k: round(x, 4) for k, x in avg.items()},
+                    "stages_ms_per_step": {k: round(x, 4) for k, x in acc.items()},
+                    "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0 and k in sb}}
+        if a.serialized:
+            ctx.set_profiling(1)
+            ser = {}
+            reps = 5
+            for i in range(reps):
+                step(i)
+                for name, ms in ctx.stage_times():
+                    ser[name] = ser.get(name, 0.0) + ms / reps
+            ctx.set_profiling(0)
+            roofline["stages_ms_serialized"] = {k: round(x, 4) for k, x in ser.items()}
         if "match_knn2" in acc:
             # the matcher is not HBM-bound.  Its distances run on the matrix cores as FP4 +-1 dot
             # products (2*256 flop per pair, dense FP4 peak ~10 PFLOP/s); its top-2 selection is one v_med3 + one
             # v_max per pair on the VALU (34 lane-ops per 16 pairs), which is the pipe that bounds it.
             pairs = B * (kp_b / B) ** 2
-            t_s = acc["match_knn2"] * 1e-3
+            t_s = avg["match_knn2"] * 1e-3
             roofline["match_mfma"] = {"bound": "mfma", "dtype": "fp4 (+-1, exact)", "pairs_per_launch": int(pairs),
                                       "achieved": round(pairs * 512 / t_s / 1e12, 1), "peak": MFMA_FP4_PEAK_TFLOPS,
                                       "unit": "TFLOP/s", "frac": round(pairs * 512 / t_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)}
@@ -254,6 +274,7 @@ def main():
                            a.width, a.height, (" + DBoW3 k=10 L=%d loop scoring vs last 64 frames%s" % (
                                a.voc_levels, " + RCCL all-gather of BoW vectors, cross-stream scores" if world > 1 else ""))
                            if a.bow else ""),
+                       "warmup_steps_run": w_eff,  # at least one per distinct batch: the warm-up also counts the keypoints
                        "frames_per_step": B, "frames_per_gpu": a.steps * B, "distinct_frames": n_unique,
                        "keypoints_per_frame": round(kp_b / B, 1), "fast_candidates_per_frame": round(cand_b / B, 1),
                        "frames_per_s": a.steps * B * world / dt_max,

@@ -210,9 +210,9 @@ int mslam_hip_debug_read(mslam_hip_ctx* ctx, int what, int frame, int level, voi
 int mslam_hip_copy_to_host(mslam_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
 /* Device timing with HIP events.  enable = 1: every stage of the last detect/match/bow batch, with
- * everything serialised on the context's stream (kernel-by-kernel analysis).  enable = 2: only the matcher
- * kernel, timed in place on the stream it runs on without changing the schedule; entries accumulate over
- * calls until they are read.  enable = 0: off.  names/ms hold up to cap entries. */
+ * everything serialised on the context's stream (kernel-by-kernel analysis).  enable = 2: every stage
+ * launch, timed in place on the stream it is launched on without changing the schedule; entries accumulate
+ * over calls until they are read.  enable = 0: off.  names/ms hold up to cap entries. */
 int mslam_hip_set_profiling(mslam_hip_ctx* ctx, int enable);
 int mslam_hip_get_stage_times(mslam_hip_ctx* ctx, const char** names, float* ms, int cap, int* n);
 

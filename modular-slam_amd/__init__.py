@@ -302,7 +302,7 @@ class Context:
         return out[:n.value].copy()
 
     def set_profiling(self, enable):
-        """0 = off, 1/True = every stage (serialised), 2 = the matcher only, in place."""
+        """0 = off, 1/True = every stage, serialised on one stream, 2 = every stage launch, in place."""
         self._chk(self.L.mslam_hip_set_profiling(self._h, int(enable)))
 
     def stage_times(self, cap=256):

@@ -619,11 +619,11 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
         if(n_chunks > 1)
             HIPCHK(c, hipStreamWaitEvent(cs, c->ev_fork, 0));
         {
-            StageScope t(c, "gray");
+            StageScope t(c, "gray", cs);
             launch_gray(d_bgr, c->d_pyr, g, f0, nf, cs);
         }
         {
-            StageScope t(c, "resize");
+            StageScope t(c, "resize", cs);
             for(int l = 1; l < g.n_levels; ++l)
             {
                 if(c->rs_q[l] != SIZE_MAX)
@@ -656,20 +656,20 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
             }
         }
         {
-            StageScope t(c, "fast");
+            StageScope t(c, "fast", cs);
             launch_fast(c->d_pyr, g, c->d_cells, c->d_cell_cnt, c->d_cell_kp, c->p.ini_fast_thr, c->p.min_fast_thr, f0,
                         nf, cs);
         }
         {
-            StageScope t(c, "quadtree");
+            StageScope t(c, "quadtree", cs);
             launch_quadtree(g, c->quad, f0, nf, cs);
         }
         {
-            StageScope t(c, "blur");
+            StageScope t(c, "blur", cs);
             launch_blur(c->d_pyr, c->d_blur, g, f0, nf, cs);
         }
         {
-            StageScope t(c, "describe");
+            StageScope t(c, "describe", cs);
             DescArgs a{};
             a.pyr = c->d_pyr;
             a.blur = c->d_blur;
@@ -812,25 +812,8 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
         m.idx1 = c->d_idx1 + (size_t)first * K;
         m.dist0 = c->d_dist0 + (size_t)first * K;
         m.dist1 = c->d_dist1 + (size_t)first * K;
-        if(c->inplace_timing && !c->profiling)
         {
-            // in-place timing of the dominant kernel on the stream it runs on (bench.py's roofline)
-            if(c->timers_used == c->timers.size())
-            {
-                StageTimer nt{"match_knn2", nullptr, nullptr};
-                HIPCHK(c, hipEventCreate(&nt.start));
-                HIPCHK(c, hipEventCreate(&nt.stop));
-                c->timers.push_back(nt);
-            }
-            StageTimer& t = c->timers[c->timers_used++];
-            t.name = "match_knn2";
-            HIPCHK(c, hipEventRecord(t.start, s));
-            launch_match_knn2(m, n_pairs, s);
-            HIPCHK(c, hipEventRecord(t.stop, s));
-        }
-        else
-        {
-            StageScope t(c, "match_knn2");
+            StageScope t(c, "match_knn2", s);
             launch_match_knn2(m, n_pairs, s);
         }
         RatioArgs r{};
@@ -845,7 +828,7 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
         r.to_idx = c->d_mto + (size_t)first * K;
         r.n_out = c->d_mcount + first;
         {
-            StageScope t(c, "ratio_compact");
+            StageScope t(c, "ratio_compact", s);
             launch_ratio_compact(r, n_pairs, s);
         }
     }

@@ -100,22 +100,27 @@ struct mslam_hip_ctx
     mslam::BowState* bow = nullptr;
 
     bool profiling = false;      // mode 1: every stage timed, everything serialised on the context's stream
-    bool inplace_timing = false; // mode 2: only the matcher is timed, in place on the stream it runs on
+    bool inplace_timing = false; // mode 2: every stage launch is timed in place on the stream it runs on
     std::vector<mslam::StageTimer> timers;
     size_t timers_used = 0;
 };
 
 namespace mslam
 {
-// records a [start, stop] HIP-event pair on the context's stream around a stage when profiling is on
+// Records a [start, stop] HIP-event pair around a stage.  Mode 1 (profiling): everything runs on the context's
+// stream, so the events go there and the stages do not overlap.  Mode 2 (inplace_timing): the events are
+// recorded on the stream the stage is launched on, which does not change the schedule; entries accumulate until
+// mslam_hip_get_stage_times reads them.
 struct StageScope
 {
     mslam_hip_ctx* c;
     mslam::StageTimer* t = nullptr;
-    StageScope(mslam_hip_ctx* ctx, const char* name) : c(ctx)
+    hipStream_t st;
+    StageScope(mslam_hip_ctx* ctx, const char* name, hipStream_t launch_stream = nullptr) : c(ctx)
     {
-        if(!c->profiling)
+        if(!c->profiling && !c->inplace_timing)
             return;
+        st = (c->profiling || !launch_stream) ? c->stream : launch_stream;
         if(c->timers_used == c->timers.size())
         {
             mslam::StageTimer nt{name, nullptr, nullptr};
@@ -125,15 +130,14 @@ struct StageScope
         }
         t = &c->timers[c->timers_used++];
         t->name = name;
-        (void)hipEventRecord(t->start, c->stream);
+        (void)hipEventRecord(t->start, st);
     }
     ~StageScope()
     {
         if(t)
-            (void)hipEventRecord(t->stop, c->stream);
+            (void)hipEventRecord(t->stop, st);
     }
 };
-
 
 // bow entry points used by api.hip
 int bow_batch(mslam_hip_ctx* c, int add_to_db);

@@ -154,21 +154,22 @@ static void launch_variant(MatchArgs a, int n_pairs, hipStream_t s)
 // Matrix-core form of the same search.  With every descriptor bit b expanded to the FP4 (E2M1) value 2b-1,
 // the dot product of two descriptors is 256 - 2*hamming, and v_mfma_scale_f32_32x32x64_f8f6f4 computes it
 // exactly (products +-1, f32 accumulation of integers below 2^24): a 32x32 tile of distances is 4 MFMAs
-// instead of 32*32*16 xor/popcount lane-operations.  The block scale of the query operand is 2^14, and the
-// accumulator starts at 257 * 2^14 + (31 - row), so what the matrix core delivers IS the sort key
-//   key(query, train j) = (dot + 257) * 2^14 + age,   age = 32 * (tiles scanned after j's tile) + 31 - (j & 31)
+// instead of 32*32*16 xor/popcount lane-operations.  The block scale of the query operand is 2^14 (the dot
+// product is even, so dot * 2^14 = (dot / 2) * 2^15), and the accumulator starts at 129 * 2^15 + (31 - row),
+// so what the matrix core delivers IS the sort key
+//   key(query, train j) = (dot / 2 + 129) * 2^15 + age,   age = 32 * (tiles scanned after j's tile) + 31 - (j & 31)
 // (larger key = smaller distance, then smaller train index: batchDistance's insertion order) and the VALU
 // only does the running top-2: one v_med3 + one v_max per pair, on the f32 bit patterns (positive floats
-// order like unsigned integers).  Keys below 2^14 mean "no neighbour".  The age field limits this kernel
-// to 16352 train rows; larger sets take the VALU kernel above.
+// order like unsigned integers).  Keys below 2^15 mean "no neighbour".  The age field limits this kernel
+// to 32736 train rows; larger sets take the VALU kernel above.
 // Queries are the B operand: the accumulator then has ONE query per lane column and 16 train rows in the
 // lane's 16 registers, so a query's top-2 stays in its lane (two lanes per query, merged at the end).
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MM_TROW = 144;          // bytes of one expanded train row in LDS: 128 + 16 (conflict-free fragment reads)
-constexpr int MM_MAX_TRAIN = 16352;   // 32 * 511: the age field is 14 bits
-constexpr float MM_KEY_UNIT = 16384.f;
+constexpr int MM_MAX_TRAIN = 32736;   // 32 * 1023: the age field is 15 bits (keys stay below 2^24: exact in f32)
+constexpr float MM_KEY_UNIT = 32768.f;
 
 template <int QT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_match_knn2_fp4(MatchArgs a)
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
     for(int i = 0; i < 16; ++i)
     {
-        cinit[i] = 257.f * MM_KEY_UNIT + (float)(31 - ((i & 3) + 8 * (i >> 2) + 4 * h));
+        cinit[i] = 129.f * MM_KEY_UNIT + (float)(31 - ((i & 3) + 8 * (i >> 2) + 4 * h));
         zero[i] = 0u;
     }
     uint32_t best0[QT], best1[QT];
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     uint32_t keyA[16], keyB[16], pend[16];
 #pragma unroll
     for(int i = 0; i < 16; ++i)
-        pend[i] = 0u; // "tile -1": keys below 2^14 never beat a real neighbour
+        pend[i] = 0u; // "tile -1": keys below 2^15 never beat a real neighbour
     uint32_t d_next;
     stage(0, fetch(0));
     d_next = fetch(1);
@@ -362,10 +363,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             const size_t o = (size_t)pair * a.cap + q;
             const int last = 32 * n_tiles - 1;
             const uint32_t k0 = (uint32_t)__uint_as_float(m0), k1 = (uint32_t)__uint_as_float(m1); // exact integers
-            a.idx0[o] = (k0 >> 14) ? last - (int)(k0 & 16383u) : -1;
-            a.idx1[o] = (k1 >> 14) ? last - (int)(k1 & 16383u) : -1;
-            a.dist0[o] = (k0 >> 14) ? (int32_t)((513u - (k0 >> 14)) >> 1) : INT_MAX;
-            a.dist1[o] = (k1 >> 14) ? (int32_t)((513u - (k1 >> 14)) >> 1) : INT_MAX;
+            // key >> 15 = dot / 2 + 129 = 257 - hamming
+            a.idx0[o] = (k0 >> 15) ? last - (int)(k0 & 32767u) : -1;
+            a.idx1[o] = (k1 >> 15) ? last - (int)(k1 & 32767u) : -1;
+            a.dist0[o] = (k0 >> 15) ? (int32_t)(257u - (k0 >> 15)) : INT_MAX;
+            a.dist1[o] = (k1 >> 15) ? (int32_t)(257u - (k1 >> 15)) : INT_MAX;
         }
     }
 }

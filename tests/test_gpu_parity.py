@@ -94,8 +94,9 @@ def test_capacity_is_loud(pkg, synth_frames):
 
 def test_match_knn2_random(orc, ctx):
     rng = np.random.default_rng(1)
-    # (17000, 130): beyond the matrix-core kernel's train range -> the xor/popcount kernel
-    for n_from, n_to in [(2000, 2000), (513, 257), (1, 5), (2, 3), (300, 1), (32, 64), (33, 600), (17000, 130)]:
+    # (33000, 70): beyond the matrix-core kernel's train range -> the xor/popcount kernel; (17000, 130): 532 tiles
+    for n_from, n_to in [(2000, 2000), (513, 257), (1, 5), (2, 3), (300, 1), (32, 64), (33, 600), (17000, 130),
+                         (33000, 70)]:
         f = rng.integers(0, 256, (n_from, 32), dtype=np.uint8)
         t = rng.integers(0, 256, (n_to, 32), dtype=np.uint8)
         got = ctx.match_knn2(f, t)
