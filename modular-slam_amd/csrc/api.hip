@@ -295,6 +295,11 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
     for(void* b : bufs)
         if(b)
             (void)hipFree(b);
+    if(c->h_out)
+        (void)hipHostFree(c->h_out);
+    for(auto& e : c->detect_graph)
+        if(e)
+            (void)hipGraphExecDestroy(e);
     if(c->stream_m)
         (void)hipStreamSynchronize(c->stream_m);
     for(auto& o : c->out)
@@ -379,6 +384,8 @@ static int create_impl(mslam_hip_ctx* c)
     }
 
     {
+        if(const char* ge = getenv("MSLAM_HIP_GRAPH"))
+            c->use_graph = atoi(ge) != 0;
         const char* e = getenv("MSLAM_HIP_STREAMS");
         c->n_side = e ? std::max(1, std::min(atoi(e), 4)) : 2; // measured in one run (batch 250): 1 / 2 / 3 / 4 chunks = 366 / 375 / 369 / 361 M kp/s
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -471,6 +478,7 @@ static int create_impl(mslam_hip_ctx* c)
     const size_t B = (size_t)p.max_batch, L = (size_t)p.n_levels, cap = (size_t)p.max_candidates;
     const size_t K = (size_t)p.max_keypoints;
     HIPCHK(c, dmalloc(c->d_stage, (size_t)p.width * p.height * 3));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out), 16 + K * 52, hipHostMallocDefault));
     // + 64: the patch loads of k_describe may run a few bytes past the last row of the last frame
     HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 64));
     HIPCHK(c, dmalloc(c->d_blur, B * g.slab + 64));
@@ -575,35 +583,12 @@ int mslam_hip_sync(mslam_hip_ctx* c)
     return check_flags(c);
 }
 
-int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
+// the kernel sequence of one detect batch into the current output set (no set switching, no events)
+static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
 {
-    ENTER(c);
-    if(!d_bgr || n_frames < 1 || n_frames > c->p.max_batch)
-        return fail(c, MSLAM_HIP_E_INVALID, "detect_batch_dev: n_frames outside [1, max_batch]");
     const Geometry& g = c->geom;
     const size_t K = (size_t)c->p.max_keypoints;
     hipStream_t s = c->stream;
-    if(!c->inplace_timing)
-        c->timers_used = 0;
-
-    // This batch goes into the other output set, so that a matcher still running on the previous batch (on
-    // its own stream) is not disturbed.  The set we are about to fill was last read by the matcher of two
-    // batches ago: wait for it.
-    if(c->n_last > 0)
-    {
-        const int prev = c->cur, nxt = prev ^ 1;
-        if(c->out[nxt].match_pending)
-        {
-            HIPCHK(c, hipStreamWaitEvent(s, c->out[nxt].ev_match, 0));
-            c->out[nxt].match_pending = false;
-        }
-        // carry the last frame of the previous batch into slot 0 (predecessor of the new frame 0)
-        const size_t last = (size_t)c->n_last;
-        HIPCHK(c, hipMemcpyAsync(c->out[nxt].desc, c->out[prev].desc + last * K * 32, K * 32, hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->out[nxt].count, c->out[prev].count + last, 4, hipMemcpyDeviceToDevice, s));
-        c->have_prev = true;
-        select_set(c, nxt);
-    }
     // Frames are independent until the matcher, so the batch is cut into chunks that run the same
     // kernel sequence on separate HIP streams: the latency-bound kernels of one chunk (quadtree, the
     // tails of every launch) overlap the throughput-bound kernels of the other.  With profiling on,
@@ -694,7 +679,49 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
         }
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->out[c->cur].ev_detect, s));
+    return MSLAM_HIP_OK;
+}
+
+// set switching + carry of the previous batch's last frame; shared by the device and the host entry points
+static int detect_prologue(mslam_hip_ctx* c)
+{
+    const size_t K = (size_t)c->p.max_keypoints;
+    hipStream_t s = c->stream;
+    if(!c->inplace_timing)
+        c->timers_used = 0;
+    // This batch goes into the other output set, so that a matcher still running on the previous batch (on
+    // its own stream) is not disturbed.  The set we are about to fill was last read by the matcher of two
+    // batches ago: wait for it.
+    if(c->n_last > 0)
+    {
+        const int prev = c->cur, nxt = prev ^ 1;
+        if(c->out[nxt].match_pending)
+        {
+            HIPCHK(c, hipStreamWaitEvent(s, c->out[nxt].ev_match, 0));
+            c->out[nxt].match_pending = false;
+        }
+        // carry the last frame of the previous batch into slot 0 (predecessor of the new frame 0)
+        const size_t last = (size_t)c->n_last;
+        HIPCHK(c, hipMemcpyAsync(c->out[nxt].desc, c->out[prev].desc + last * K * 32, K * 32, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->out[nxt].count, c->out[prev].count + last, 4, hipMemcpyDeviceToDevice, s));
+        c->have_prev = true;
+        select_set(c, nxt);
+    }
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
+{
+    ENTER(c);
+    if(!d_bgr || n_frames < 1 || n_frames > c->p.max_batch)
+        return fail(c, MSLAM_HIP_E_INVALID, "detect_batch_dev: n_frames outside [1, max_batch]");
+    int rc = detect_prologue(c);
+    if(rc)
+        return rc;
+    rc = enqueue_detect(c, d_bgr, n_frames);
+    if(rc)
+        return rc;
+    HIPCHK(c, hipEventRecord(c->out[c->cur].ev_detect, c->stream));
     c->n_last = n_frames;
     return MSLAM_HIP_OK;
 }
@@ -729,28 +756,85 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     if(width != c->p.width || height != c->p.height)
         return fail(c, MSLAM_HIP_E_INVALID, "detect: frame size differs from the context's");
     const size_t K = (size_t)c->p.max_keypoints;
+    // Results come back through one pinned staging block: count, flags and all five arrays are queued as
+    // asynchronous copies behind the kernels and ONE synchronisation covers them (a synchronous hipMemcpy per
+    // array costs a round trip each), then the first n entries are handed to the caller's buffers.
+    uint8_t* h = c->h_out;
+    uint8_t* h_xy = h + 16;
+    uint8_t* h_desc = h_xy + K * 8;
+    uint8_t* h_oct = h_desc + K * 32;
+    uint8_t* h_ang = h_oct + K * 4;
+    uint8_t* h_resp = h_ang + K * 4;
+    auto enqueue_results = [&](size_t cap) -> int {
+        HIPCHK(c, hipMemcpyAsync(h, c->d_count + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h + 4, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+        if(cap > 0)
+        {
+            HIPCHK(c, hipMemcpyAsync(h_xy, c->d_xy + K * 2, cap * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_desc, c->d_desc + K * 32, cap * 32, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_oct, c->d_octave + K, cap * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_ang, c->d_angle + K, cap * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(h_resp, c->d_response + K, cap * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        return MSLAM_HIP_OK;
+    };
+    HIPCHK(c, hipStreamSynchronize(c->stream_m));
     HIPCHK(c, hipMemcpyAsync(c->d_stage, bgr, (size_t)width * height * 3, hipMemcpyHostToDevice, c->stream));
-    int rc = mslam_hip_detect_batch_dev(c, c->d_stage, 1);
+    int rc = detect_prologue(c);
     if(rc)
         return rc;
-    int32_t n = 0;
-    HIPCHK(c, hipMemcpyAsync(&n, c->d_count + 1, 4, hipMemcpyDeviceToHost, c->stream));
-    rc = check_flags(c); // synchronises
-    if(rc)
-        return rc;
+    // The single-frame call is launch-bound (12 small kernels + 7 copies), so its fixed sequence is captured
+    // once per output set into a HIP graph and replayed.  With stage timing on, the plain path runs.
+    if(!c->profiling && !c->inplace_timing && c->use_graph)
+    {
+        hipGraphExec_t& exec = c->detect_graph[c->cur];
+        if(!exec)
+        {
+            hipGraph_t graph = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            rc = enqueue_detect(c, c->d_stage, 1);
+            if(!rc)
+                rc = enqueue_results(K);
+            const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+            if(rc)
+                return rc;
+            HIPCHK(c, e);
+            HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+        }
+        HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    }
+    else
+    {
+        rc = enqueue_detect(c, c->d_stage, 1);
+        if(rc)
+            return rc;
+        rc = enqueue_results(std::min<size_t>(K, (size_t)max_out));
+        if(rc)
+            return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->out[c->cur].ev_detect, c->stream));
+    c->n_last = 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t flags;
+    int32_t n;
+    std::memcpy(&n, h, 4);
+    std::memcpy(&flags, h + 4, 4);
+    if(flags)
+        return check_flags(c); // reads the flags again, clears them and reports
     *n_out = n;
     if(n > max_out)
         return fail(c, MSLAM_HIP_E_CAPACITY, "detect: max_out smaller than the number of keypoints");
     if(n == 0)
         return MSLAM_HIP_OK;
-    HIPCHK(c, hipMemcpy(xy, c->d_xy + K * 2, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(desc, c->d_desc + K * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    std::memcpy(xy, h_xy, (size_t)n * 8);
+    std::memcpy(desc, h_desc, (size_t)n * 32);
     if(octave)
-        HIPCHK(c, hipMemcpy(octave, c->d_octave + K, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::memcpy(octave, h_oct, (size_t)n * 4);
     if(angle)
-        HIPCHK(c, hipMemcpy(angle, c->d_angle + K, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::memcpy(angle, h_ang, (size_t)n * 4);
     if(response)
-        HIPCHK(c, hipMemcpy(response, c->d_response + K, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::memcpy(response, h_resp, (size_t)n * 4);
     return MSLAM_HIP_OK;
 }
 
@@ -947,12 +1031,26 @@ int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, cons
     launch_ratio_compact(r, 1, c->stream);
     HIPCHK(c, hipGetLastError());
     int32_t n = 0;
-    HIPCHK(c, hipMemcpyAsync(&n, r.n_out, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if(n > 0)
+    const size_t K = (size_t)c->p.max_keypoints, words = 2 * cap + 1; // from_idx | to_idx | n_out are contiguous
+    if(words * 4 <= 16 + K * 52)
     {
-        HIPCHK(c, hipMemcpy(from_idx, r.from_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(to_idx, r.to_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
+        // one asynchronous copy of all three into the pinned staging block, one synchronisation
+        int32_t* h = reinterpret_cast<int32_t*>(c->h_out);
+        HIPCHK(c, hipMemcpyAsync(h, r.from_idx, words * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        n = h[2 * cap];
+        std::memcpy(from_idx, h, (size_t)n * 4);
+        std::memcpy(to_idx, h + cap, (size_t)n * 4);
+    }
+    else
+    {
+        HIPCHK(c, hipMemcpyAsync(&n, r.n_out, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if(n > 0)
+        {
+            HIPCHK(c, hipMemcpy(from_idx, r.from_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(to_idx, r.to_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
+        }
     }
     *n_out = n;
     return MSLAM_HIP_OK;

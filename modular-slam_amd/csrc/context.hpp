@@ -59,6 +59,9 @@ struct mslam_hip_ctx
     std::vector<int> rs_need;       // per level: which pixel positions of a quad ever use the upper dword pair
     int32_t* d_ratio_thr = nullptr; // [257]
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
+    hipGraphExec_t detect_graph[2] = {nullptr, nullptr}; // mslam_hip_detect's kernel + copy sequence, per output set
+    bool use_graph = true;
+    uint8_t* h_out = nullptr;       // pinned staging of mslam_hip_detect's results: [count, flags | xy | desc | octave | angle | response] for K keypoints
     double ratio_cached = -1.0;
 
     // device working set (sized for max_batch frames)
