@@ -3,10 +3,13 @@
 // then the call order of RgbdFeatureFrontend::processSensorData: detect(frame_t) ->
 // match(from = keypoints_t, to = keypoints_{t-1}) (rgbd_feature_frontend.cpp:187,237).
 //
-// usage: mslam_harness <plugin.so> <width> <height> <frame0.bgr> <frame1.bgr> [--load-only]
+// usage: mslam_harness <plugin.so> <width> <height> <frame0.bgr> <frame1.bgr>     raw B,G,R frames
+//        mslam_harness <plugin.so> --tum <associations.txt>                       a TUM RGB-D sequence, read the way
+//                                                                                 the reference's RgbdFileProvider does
 // prints one line per frame/match with an FNV-1a checksum the parity test compares with the oracle's.
 #include "mslam_interfaces.hpp"
 #include "plugin_loader.hpp"
+#include "tum_io.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -36,20 +39,37 @@ int main(int argc, char** argv)
         std::unique_ptr<mslam::IOrbFeatureDetector> detector = makeDetector();
         std::unique_ptr<mslam::IOrbMatcher> matcher = makeMatcher();
         std::printf("loaded %s\n", detector && matcher ? "ok" : "null");
-        if(argc < 6)
+        const bool tum = argc == 4 && std::strcmp(argv[2], "--tum") == 0;
+        if(argc < 6 && !tum)
             return detector && matcher ? 0 : 4;
-        const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+        const int w = tum ? 0 : std::atoi(argv[2]), h = tum ? 0 : std::atoi(argv[3]);
+        mslam::RgbdFileProvider provider(tum ? mslam::readTumRgbdDataset(argv[3]) : mslam::RgbdFilePaths{},
+                                         mslam::tumRgbdCameraParams());
+        if(tum && !provider.init())
+        {
+            std::fprintf(stderr, "no frames listed in %s\n", argv[3]);
+            return 5;
+        }
         std::vector<mslam::OrbKeypoint> prev;
-        for(int f = 0; f < 2; ++f)
+        for(int f = 0; tum ? provider.fetch() : f < 2; ++f)
         {
             mslam::RgbFrame frame;
-            frame.size = {w, h};
-            frame.data.resize(static_cast<std::size_t>(w) * h * 3);
-            std::ifstream in(argv[4 + f], std::ios::binary);
-            if(!in.read(reinterpret_cast<char*>(frame.data.data()), static_cast<std::streamsize>(frame.data.size())))
+            if(tum)
             {
-                std::fprintf(stderr, "cannot read %s\n", argv[4 + f]);
-                return 5;
+                const auto data = provider.recentData();
+                frame.size = {data->width, data->height};
+                frame.data = data->rgb;
+            }
+            else
+            {
+                frame.size = {w, h};
+                frame.data.resize(static_cast<std::size_t>(w) * h * 3);
+                std::ifstream in(argv[4 + f], std::ios::binary);
+                if(!in.read(reinterpret_cast<char*>(frame.data.data()), static_cast<std::streamsize>(frame.data.size())))
+                {
+                    std::fprintf(stderr, "cannot read %s\n", argv[4 + f]);
+                    return 5;
+                }
             }
             auto kps = detector->detect(frame);
             std::uint32_t hc = 0x811C9DC5u;

@@ -68,3 +68,8 @@ def test_plugin_detect_match_parity(built, orc, bundled_frames, tmp_path):
     for a, b in zip(fi, ti):
         h = _fnv(struct.pack("<QQ", int(a), int(b)), h)
     assert "match 1 pairs %d fnv %08x" % (len(fi), h) in lines
+    # the same two frames as a TUM RGB-D sequence (PNG files + association list) give the same lines
+    assoc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tum", "associations.txt")
+    r2 = subprocess.run([HARNESS, PLUGIN, "--tum", assoc], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    assert r2.stdout.strip().splitlines() == lines
