@@ -123,6 +123,8 @@ struct StageScope
     {
         if(!c->profiling && !c->inplace_timing)
             return;
+        if(c->timers_used >= 8192)
+            return; // mode 2 accumulates until read: bound the number of live events
         st = (c->profiling || !launch_stream) ? c->stream : launch_stream;
         if(c->timers_used == c->timers.size())
         {
