@@ -86,15 +86,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         n_cand = 0;
 
     // stage the sub-image: aligned global dwords start at column x0 - 3 (x0 = 19 + 64 j), the LDS image is
-    // shifted by two bytes (v_alignbyte) so that the tested columns are dword aligned in LDS
+    // shifted by two bytes (v_alignbyte) so that the tested columns are dword aligned in LDS.  One 12-byte load
+    // per lane yields two LDS dwords (LDS dword q = global bytes 4q+2 .. 4q+5): 10 lanes per 76-byte row, so a
+    // wave-load spans 6.4 rows instead of the 3.4 of a dword-per-lane copy that also fetched every dword twice —
+    // the texture path charges per row segment touched.
     {
         const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - 3);
-        const int n_dw = ch * 19;
-        for(int i = tid; i < n_dw; i += 256)
+        const int n_items = ch * 10;
+        for(int i = tid; i < n_items; i += 256)
         {
-            const int r = i / 19, q = i - r * 19;
-            const uint32_t* gp = reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 4 * q);
-            reinterpret_cast<uint32_t*>(tile)[i] = __builtin_amdgcn_alignbyte(gp[1], gp[0], 2);
+            const int r = (i * 6554) >> 16, j = i - r * 10; // i / 10 for i < 16384
+            const uint32_t* gp = reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 8 * j);
+            const uint32_t g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            uint32_t* t = reinterpret_cast<uint32_t*>(tile) + r * 19 + 2 * j;
+            t[0] = __builtin_amdgcn_alignbyte(g1, g0, 2);
+            if(j < 9) // dword 19 does not exist
+                t[1] = __builtin_amdgcn_alignbyte(g2, g1, 2);
         }
     }
     __syncthreads();
