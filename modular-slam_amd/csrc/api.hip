@@ -480,8 +480,8 @@ static int create_impl(mslam_hip_ctx* c)
     HIPCHK(c, dmalloc(c->d_stage, (size_t)p.width * p.height * 3));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out), 16 + K * 52, hipHostMallocDefault));
     // + 64: the patch loads of k_describe may run a few bytes past the last row of the last frame
-    HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 64));
-    HIPCHK(c, dmalloc(c->d_blur, B * g.slab + 64));
+    HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 256));
+    HIPCHK(c, dmalloc(c->d_blur, B * g.slab + 256));
     HIPCHK(c, dmalloc(c->d_cell_cnt, B * g.n_cells));
     HIPCHK(c, dmalloc(c->d_cell_kp, B * g.n_cells * (size_t)kCellCap));
     QuadArgs& q = c->quad;

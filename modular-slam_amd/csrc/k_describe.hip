@@ -74,7 +74,8 @@ __device__ __forceinline__ float util_sin(float v)
 
 constexpr int kPatchR = 19;               // sample radius of the rotated pattern (orb_patch_radius_)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 39
-constexpr int kPatchDw = 11;              // 44 aligned bytes per staged row cover the 39 needed ones
+constexpr int kPatchDw = 16;              // 64 bytes from a 16-byte aligned start cover the 39 needed ones
+constexpr int kPatchBufs = 3;            // LDS patch ring per wave: one being sampled, two in flight
 constexpr int kBlocksPerFrame = 32;
 
 // 64-lane integer sum with DPP adds (VALU only, no LDS crossbar); the total lands in lane 63
@@ -118,7 +119,7 @@ constexpr int kWavesPerFrame = kBlocksPerFrame * 4;
 
 __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
 {
-    __shared__ uint32_t patch[4][2][kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t patch[4][kPatchBufs][kPatchRows * kPatchDw];
 
     // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, so all kBlocksPerFrame
     // workgroups of a frame are given ids with the same (id & 7): the two level slabs of a frame (1.9 MB)
@@ -256,40 +257,33 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
 
         // ---- C. descriptors
         {
-            auto load_patch = [&](int k, uint32_t (&r)[7]) {
+            // The 39 x 39 blurred patch comes in as 39 rows x 64 bytes from a 16-byte aligned start, by LDS-DMA
+            // (global_load_lds_dwordx4: per-lane source address, lane-linear destination, no VGPRs): lane t of
+            // instruction q fetches 16-byte chunk (t + 64 q) & 3 of row (t + 64 q) >> 2, which lands at byte
+            // 16 (t + 64 q) of the patch — exactly row-major with a 64-byte pitch.  Three DMA instructions per
+            // keypoint instead of seven register loads + seven LDS stores, and the patches of the next two
+            // keypoints are in flight while one is sampled.
+            auto dma_patch = [&](int k, int buf) {
                 int px, py;
                 const LevelGeom& lv = kp_of(k, px, py);
-                const int bx0 = px - kPatchR, sh = bx0 & 3;
-                const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * lv.pitch + (bx0 - sh);
-                const uint32_t* bsrc32 = reinterpret_cast<const uint32_t*>(bsrc); // wave-uniform base, 32-bit lane offsets
+                const int bx0 = px - kPatchR;
+                const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * lv.pitch + (bx0 & ~15);
                 const uint32_t pitch = (uint32_t)lv.pitch;
 #pragma unroll
-                for(int q = 0; q < 7; ++q)
+                for(int q = 0; q < 3; ++q)
                 {
                     const uint32_t t = (uint32_t)lane + 64u * q;
-                    r[q] = 0;
-                    if(t < (uint32_t)(kPatchRows * kPatchDw))
-                    {
-                        const uint32_t row = (t * 5958u) >> 16; // t / 11 for t < 429
-                        const uint32_t col = t - row * kPatchDw;
-                        r[q] = bsrc32[(__umul24(row, pitch) >> 2) + col];
-                    }
-                }
-            };
-            auto store_patch = [&](int buf, const uint32_t (&r)[7]) {
-#pragma unroll
-                for(int q = 0; q < 7; ++q)
-                {
-                    const uint32_t t = (uint32_t)lane + 64u * q;
-                    if(t < (uint32_t)(kPatchRows * kPatchDw))
-                        patch[wave][buf][t] = r[q];
+                    if(t < (uint32_t)(kPatchRows * 4))
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(bsrc + __umul24(t >> 2, pitch) + 16u * (t & 3u)),
+                            (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
                 }
             };
             auto describe = [&](int k, int buf) {
                 const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ca), k));
                 const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sa), k));
                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)my_kp, k);
-                const int sh = (kp_x(p) + kBorder - kPatchR) & 3;
+                const int sh = (kp_x(p) + kBorder - kPatchR) & 15;
                 const uint8_t* bc =
                     reinterpret_cast<const uint8_t*>(patch[wave][buf]) + kPatchR * (kPatchDw * 4) + kPatchR + sh; // centre
                 unsigned long long bits[4];
@@ -315,24 +309,26 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k) * 32)[lane] = w;
                 }
             };
-            uint32_t r0[7], r1[7];
-            load_patch(0, r0);
+            dma_patch(0, 0);
             if(1 < n_here)
-                load_patch(1, r1);
-            for(int k = 0; k < n_here; k += 2)
+                dma_patch(1, 1);
+            for(int k = 0; k < n_here; ++k)
             {
-                __builtin_amdgcn_wave_barrier(); // the previous pair's gathers are done before the patches are overwritten
-                store_patch(0, r0);
-                if(k + 1 < n_here)
-                    store_patch(1, r1);
+                // patch k must have landed: LDS-DMA is counted by vmcnt, in issue order, so "at most the DMAs issued
+                // after it outstanding" is the condition (3 instructions per patch; a younger store only makes the
+                // wait a little longer than necessary)
                 if(k + 2 < n_here)
-                    load_patch(k + 2, r0);
-                if(k + 3 < n_here)
-                    load_patch(k + 3, r1);
+                {
+                    dma_patch(k + 2, (k + 2) % kPatchBufs); // its ring slot was sampled in iteration k - 1
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+                }
+                else if(k + 1 < n_here)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 3);
+                else
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
                 __builtin_amdgcn_wave_barrier();
-                describe(k, 0);
-                if(k + 1 < n_here)
-                    describe(k + 1, 1);
+                describe(k, k % kPatchBufs);
+                __builtin_amdgcn_wave_barrier(); // the gathers are done before the slot is refilled
             }
         }
     }
