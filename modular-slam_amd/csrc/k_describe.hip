@@ -75,7 +75,7 @@ __device__ __forceinline__ float util_sin(float v)
 constexpr int kPatchR = 19;               // sample radius of the rotated pattern (orb_patch_radius_)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 39
 constexpr int kPatchDw = 16;              // 64 bytes from a 16-byte aligned start cover the 39 needed ones
-constexpr int kPatchBufs = 3;            // LDS patch ring per wave: one being sampled, two in flight
+constexpr int kPatchBufs = 4;            // LDS patch ring per wave: one being sampled, three in flight (2 / 3 / 4 / 5 / 6 slots: 0.59 / 0.56 / 0.55 / 0.57 / 0.68 ms per 500 frames)
 constexpr int kBlocksPerFrame = 32;
 
 // 64-lane integer sum with DPP adds (VALU only, no LDS crossbar); the total lands in lane 63
@@ -309,20 +309,29 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k) * 32)[lane] = w;
                 }
             };
-            dma_patch(0, 0);
-            if(1 < n_here)
-                dma_patch(1, 1);
+            constexpr int kDepth = kPatchBufs - 1; // patches in flight beside the one being sampled
+            static_assert(kDepth >= 1 && kDepth <= 5, "the vmcnt immediates below cover up to 5 patches in flight");
+#pragma unroll
+            for(int i = 0; i < kDepth; ++i)
+                if(i < n_here)
+                    dma_patch(i, i);
             for(int k = 0; k < n_here; ++k)
             {
                 // patch k must have landed: LDS-DMA is counted by vmcnt, in issue order, so "at most the DMAs issued
                 // after it outstanding" is the condition (3 instructions per patch; a younger store only makes the
                 // wait a little longer than necessary)
-                if(k + 2 < n_here)
-                {
-                    dma_patch(k + 2, (k + 2) % kPatchBufs); // its ring slot was sampled in iteration k - 1
+                const int younger = min(kDepth, n_here - 1 - k);
+                if(k + kDepth < n_here)
+                    dma_patch(k + kDepth, (k + kDepth) % kPatchBufs); // its ring slot was sampled in iteration k - 1
+                if(younger >= 5)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 15);
+                else if(younger == 4)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 12);
+                else if(younger == 3)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 9);
+                else if(younger == 2)
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
-                }
-                else if(k + 1 < n_here)
+                else if(younger == 1)
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 3);
                 else
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
