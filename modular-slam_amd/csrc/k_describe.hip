@@ -90,12 +90,6 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p)
-{
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
 
 // Every WAVE is an independent worker (no workgroup barriers): it takes kBatch keypoints at a time through
 //  0. one LANE per keypoint: which level, which candidate word (kept in that lane's registers and
@@ -191,48 +185,70 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
         // ---- A. moments
         int my_m10 = 0, my_m01 = 0;
         {
-            auto fetch = [&](int k, uint32_t (&dw)[4]) {
+            // the 31 x 31 window of the unblurred level comes in by LDS-DMA as 31 rows x 48 bytes from a 16-byte
+            // aligned start (two global_load_lds_dwordx4 per keypoint into the ring phase C uses later); lane t (+64q)
+            // then reads dword (row t/8, column group t%8) of the window as two aligned LDS dwords + v_alignbyte
+            auto dma_disc = [&](int k, int buf) {
                 int px, py;
                 const LevelGeom& lv = kp_of(k, px, py);
-                const uint8_t* raw = pyr + lv.offset + (py - 15) * lv.pitch + (px - 15);
+                const uint8_t* src = pyr + lv.offset + (py - 15) * lv.pitch + ((px - 15) & ~15);
+                const uint32_t pitch = (uint32_t)lv.pitch;
 #pragma unroll
-                for(int q = 0; q < 4; ++q)
+                for(int q = 0; q < 2; ++q)
                 {
-                    const int t = lane + 64 * q;
-                    dw[q] = t < 31 * 8 ? load_u32_unaligned(raw + (t >> 3) * lv.pitch + 4 * (t & 7)) : 0x80808080u;
+                    const uint32_t t = (uint32_t)lane + 64u * q;
+                    if(t < 93u)
+                    {
+                        const uint32_t row = (t * 21846u) >> 16; // t / 3
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(src + __umul24(row, pitch) + 16u * (t - 3u * row)),
+                            (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                    }
                 }
             };
-            auto reduce = [&](int k, const uint32_t (&dw)[4]) {
+            auto reduce = [&](int k, int buf) {
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)my_kp, k);
+                const int sh = (kp_x(p) + kBorder - 15) & 15;
+                const uint32_t* d = patch[wave][buf] + (sh >> 2);
                 int m10 = 0, m01 = 0;
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
                 {
-                    const uint32_t x = dw[q] ^ 0x80808080u;
+                    const int t = lane + 64 * q;
+                    uint32_t x = 0x80808080u;
+                    if(t < 31 * 8)
+                    {
+                        const uint32_t* e = d + (t >> 3) * 12 + (t & 7);
+                        x = __builtin_amdgcn_alignbyte(e[1], e[0], sh & 3);
+                    }
+                    x ^= 0x80808080u;
                     m10 = __builtin_amdgcn_sdot4((int)x, (int)wu[q], m10, false);
                     m01 = __builtin_amdgcn_sdot4((int)x, (int)wv[q], m01, false);
                 }
                 { const int t10 = wave_sum_dpp(m10); my_m10 = lane == k ? t10 : my_m10; }
                 { const int t01 = wave_sum_dpp(m01); my_m01 = lane == k ? t01 : my_m01; }
             };
-            uint32_t c0[4], c1[4], n0[4], n1[4];
-            fetch(0, c0);
-            if(1 < n_here)
-                fetch(1, c1);
-            for(int k = 0; k < n_here; k += 2)
-            {
-                if(k + 2 < n_here)
-                    fetch(k + 2, n0);
-                if(k + 3 < n_here)
-                    fetch(k + 3, n1);
-                reduce(k, c0);
-                if(k + 1 < n_here)
-                    reduce(k + 1, c1);
+            constexpr int kDepthA = kPatchBufs - 1;
 #pragma unroll
-                for(int q = 0; q < 4; ++q)
-                {
-                    c0[q] = n0[q];
-                    c1[q] = n1[q];
-                }
+            for(int i = 0; i < kDepthA; ++i)
+                if(i < n_here)
+                    dma_disc(i, i);
+            for(int k = 0; k < n_here; ++k)
+            {
+                const int younger = min(kDepthA, n_here - 1 - k); // windows issued after window k: 2 DMAs each
+                if(k + kDepthA < n_here)
+                    dma_disc(k + kDepthA, (k + kDepthA) % kPatchBufs);
+                if(younger >= 3)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+                else if(younger == 2)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+                else if(younger == 1)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 2);
+                else
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
+                __builtin_amdgcn_wave_barrier();
+                reduce(k, k % kPatchBufs);
+                __builtin_amdgcn_wave_barrier(); // the reads are done before the slot is refilled
             }
         }
 
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 }
             };
             constexpr int kDepth = kPatchBufs - 1; // patches in flight beside the one being sampled
+            static_assert(kPatchBufs == 4, "phase A's vmcnt immediates are written for three windows in flight");
             static_assert(kDepth >= 1 && kDepth <= 5, "the vmcnt immediates below cover up to 5 patches in flight");
 #pragma unroll
             for(int i = 0; i < kDepth; ++i)
