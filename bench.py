@@ -42,7 +42,7 @@ def pmc_traffic(stage, kernels_per_launch, frames_per_launch):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced
     streaming reads — MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known
-    input confirms: 250 frames x 921 600 B = 230.4 MB, FETCH_SIZE reads 115.2 MB).  None when no profile
+    input confirms: 500 frames x 921 600 B = 460.8 MB, FETCH_SIZE reads 230.4 MB).  None when no profile
     is committed.  `kernels_per_launch`: the resize stage is 7 kernels (one per level) timed as one."""
     path = os.path.join(ROOT, "profiles", "r01_e_pmc_fetch_write_per_launch.json")
     try:
@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=500, help="frames per step (2 steps = the 1000-frame stream of cfg2)")
+    ap.add_argument("--batch", type=int, default=1000, help="frames per step (one step = the 1000-frame stream of cfg2)")
     ap.add_argument("--unique", type=int, default=1000, help="distinct synthetic frames kept in HBM (cycled)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
