@@ -95,12 +95,15 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t* __restrict__
         return; // whole 16-lane group leaves together
     const uint4* q = reinterpret_cast<const uint4*>(desc + (long long)frame * desc_stride + (size_t)i * 32);
     const uint4 qa = q[0], qb = q[1];
+    // One dependent memory round trip per tree level: lane c fetches child c's descriptor AND child c's own
+    // (first child, child count) together; after the argmin the winner's pair comes from the winning lane by
+    // shuffle instead of from memory (first[] -> children -> nchild[] used to be three round trips per level).
     uint32_t node = 0;
-    uint32_t nc = nchild[0];
+    uint32_t fc = first[0], nc = nchild[0];
     while(nc != 0)
     {
-        const uint32_t fc = first[node];
         uint32_t best = 0xFFFFFFFFu; // (distance << 16) | child index: min == first child with the least distance
+        uint32_t best_fc = 0, best_nc = 0;
         for(uint32_t c0 = 0; c0 < nc; c0 += kBowGroup)
         {
             const uint32_t c = c0 + sub;
@@ -108,16 +111,27 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t* __restrict__
             {
                 const uint4* t = tdesc + (size_t)(fc + c) * 2;
                 const uint4 ta = t[0], tb = t[1];
+                const uint32_t cf = first[fc + c], cn = nchild[fc + c];
                 const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
                                    __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-                best = min(best, (d << 16) | c);
+                const uint32_t key = (d << 16) | c;
+                if(key < best)
+                {
+                    best = key;
+                    best_fc = cf;
+                    best_nc = cn;
+                }
             }
         }
+        uint32_t all = best;
 #pragma unroll
         for(int o = kBowGroup / 2; o > 0; o >>= 1)
-            best = min(best, (uint32_t)__shfl_xor((int)best, o, kBowGroup));
-        node = fc + (best & 0xFFFFu);
-        nc = nchild[node];
+            all = min(all, (uint32_t)__shfl_xor((int)all, o, kBowGroup));
+        // keys are unique (they carry the child index): exactly one lane of the group holds the winner
+        const int src = (int)((all & 0xFFFFu) % kBowGroup); // the lane that scored child (all & 0xFFFF)
+        node = fc + (all & 0xFFFFu);
+        fc = (uint32_t)__shfl((int)best_fc, src, kBowGroup);
+        nc = (uint32_t)__shfl((int)best_nc, src, kBowGroup);
     }
     if(sub == 0)
     {
