@@ -130,16 +130,18 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         if(i >= 6)
         {
             // vertical pass for output row o = y0 + i - 6: source rows i-6 .. i
-            uint32_t out = 0;
+            uint32_t acc[4];
 #pragma unroll
             for(int j = 0; j < 4; ++j)
             {
-                uint32_t acc = dot2u(pr[(i - 6) % 6][j], t01, 32768u);
-                acc = dot2u(pr[(i - 4) % 6][j], t23, acc);
-                acc = dot2u(pr[(i - 2) % 6][j], t45, acc);
-                acc += hv[j] * t6;
-                out |= (acc >> 16) << (8 * j);
+                acc[j] = dot2u(pr[(i - 6) % 6][j], t01, 32768u);
+                acc[j] = dot2u(pr[(i - 4) % 6][j], t23, acc[j]);
+                acc[j] = dot2u(pr[(i - 2) % 6][j], t45, acc[j]);
+                acc[j] += hv[j] * t6;
             }
+            // the result (acc >> 16, at most 255) is byte 2 of each accumulator: two v_perm gather the four bytes
+            const uint32_t out = __builtin_amdgcn_perm(acc[1], acc[0], 0x0C0C0602u) |
+                                 __builtin_amdgcn_perm(acc[3], acc[2], 0x06020C0Cu);
             const int o = y0 + i - 6;
             if(o < h)
                 *reinterpret_cast<uint32_t*>(dst + (size_t)o * pitch + x0) = out;
