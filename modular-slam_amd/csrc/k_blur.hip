@@ -57,8 +57,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const int y0 = band * kBlurRows;
     const int w = lv.w, h = lv.h, pitch = lv.pitch;
     const size_t frame = blockIdx.y + g.frame0;
-    const uint8_t* src = pyr + frame * g.slab + lv.offset;
-    uint8_t* dst = blur + frame * g.slab + lv.offset;
+    // wave-uniform frame bases + 32-bit per-lane offsets (the level differs between lanes): loads and stores take the
+    // SGPR-base + VGPR-offset form and no 64-bit address arithmetic is needed per row
+    const uint8_t* src = pyr + frame * g.slab;
+    uint8_t* dst = blur + frame * g.slab;
+    const uint32_t lofs = (uint32_t)lv.offset;
 
     // ---- per-lane REFLECT_101 selectors for the 12-byte window [x0-4, x0+8)
     uint32_t selA = 0, selB = 0, selT = 0, selU = 0, maskT = 0;
@@ -100,13 +103,15 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 #pragma unroll
     for(int i = 0; i < kBlurRows + 6; ++i)
     {
-        int yy = y0 - 3 + i;
-        yy = yy < 0 ? -yy : yy;
-        yy = yy >= h ? 2 * (h - 1) - yy : yy;
-        const uint8_t* row = src + (size_t)yy * pitch;
-        const uint32_t A = *reinterpret_cast<const uint32_t*>(row + offA);
-        const uint32_t B = *reinterpret_cast<const uint32_t*>(row + x0);
-        const uint32_t C = *reinterpret_cast<const uint32_t*>(row + offC);
+        // REFLECT_101 of the row index without compare/select pairs: |y|, then min(y, 2 (h - 1) - y)
+        const int ya = max(y0 - 3 + i, -(y0 - 3 + i));
+        const int yy = min(ya, 2 * (h - 1) - ya);
+        // 32-bit offsets from the (wave-uniform) level base: one 24-bit multiply per row instead of 64-bit
+        // address arithmetic per load
+        const uint32_t ro = lofs + __umul24((uint32_t)yy, (uint32_t)pitch);
+        const uint32_t A = *reinterpret_cast<const uint32_t*>(src + (ro + (uint32_t)offA));
+        const uint32_t B = *reinterpret_cast<const uint32_t*>(src + (ro + (uint32_t)x0));
+        const uint32_t C = *reinterpret_cast<const uint32_t*>(src + (ro + (uint32_t)offC));
         const uint32_t A2 = __builtin_amdgcn_perm(B, A, selA);
         const uint32_t B2 = __builtin_amdgcn_perm(B, A, selB);
         const uint32_t T = __builtin_amdgcn_perm(B, A, selT);
@@ -137,14 +142,14 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                 acc[j] = dot2u(pr[(i - 6) % 6][j], t01, 32768u);
                 acc[j] = dot2u(pr[(i - 4) % 6][j], t23, acc[j]);
                 acc[j] = dot2u(pr[(i - 2) % 6][j], t45, acc[j]);
-                acc[j] += hv[j] * t6;
+                acc[j] += __umul24(hv[j], t6); // hv <= 65280, tap <= 255: the 24-bit multiply-add is full rate
             }
             // the result (acc >> 16, at most 255) is byte 2 of each accumulator: two v_perm gather the four bytes
             const uint32_t out = __builtin_amdgcn_perm(acc[1], acc[0], 0x0C0C0602u) |
                                  __builtin_amdgcn_perm(acc[3], acc[2], 0x06020C0Cu);
             const int o = y0 + i - 6;
             if(o < h)
-                *reinterpret_cast<uint32_t*>(dst + (size_t)o * pitch + x0) = out;
+                *reinterpret_cast<uint32_t*>(dst + (lofs + __umul24((uint32_t)o, (uint32_t)pitch) + (uint32_t)x0)) = out;
         }
 #pragma unroll
         for(int j = 0; j < 4; ++j)
