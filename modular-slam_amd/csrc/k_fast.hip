@@ -171,13 +171,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                     base = __builtin_amdgcn_readfirstlane(base);
                     uint32_t pos = base + inc - cnt;
                     const uint32_t yx = (uint32_t)((y << 8) | xl);
-                    cand[(keep & 1u) ? pos : kDump] = (uint16_t)yx;
-                    pos += keep & 1u;
-                    cand[(keep & 2u) ? pos : kDump] = (uint16_t)(yx + 1);
-                    pos += (keep >> 1) & 1u;
-                    cand[(keep & 4u) ? pos : kDump] = (uint16_t)(yx + 2);
-                    pos += (keep >> 2) & 1u;
-                    cand[(keep & 8u) ? pos : kDump] = (uint16_t)(yx + 3);
+                    // slot = kept ? pos : dump as ONE v_bfi_b32 on an all-ones / all-zeros mask (v_bfe_i32), and the
+                    // running slot advanced with a 24-bit multiply-add on the same mask: 3 VALU ops per store instead of
+                    // the compare + select + shift chains the compiler builds (which also cost wait states here)
+                    uint32_t pos2 = 2u * pos; // byte offset into cand[]
+                    const uint32_t dump2 = 2u * kDump;
+#pragma unroll
+                    for(int k = 0; k < 4; ++k)
+                    {
+                        const int m = __builtin_amdgcn_sbfe((int)keep, k, 1); // -1 when kept
+                        uint32_t slot2;
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(slot2) : "v"(m), "v"(pos2), "v"(dump2));
+                        *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(cand) + slot2) = (uint16_t)(yx + k);
+                        pos2 = (uint32_t)__mul24(m, -2) + pos2;
+                    }
                 }
             }
         }
