@@ -30,19 +30,26 @@ struct Scan
     uint32_t wsum[QT / 64];
 };
 
+// inclusive prefix sum over the 64 lanes of a wave with DPP adds (VALU only; __shfl_up would take six trips through
+// the LDS crossbar)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xE, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xC, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); // row_bcast:31
+    return (uint32_t)x;
+}
+
 // exclusive scan of one value per thread across the workgroup; returns the exclusive prefix, `total`
 // receives the workgroup sum.  Two barriers; `s` may be reused right after return.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Scan& s, uint32_t& total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for(int o = 1; o < 64; o <<= 1)
-    {
-        const uint32_t t = __shfl_up(inc, o);
-        if(lane >= o)
-            inc += t;
-    }
+    const uint32_t inc = wave_incl_scan(v);
     if(lane == 63)
         s.wsum[wave] = inc;
     __syncthreads();
@@ -65,17 +72,7 @@ __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, Scan& s
                                                  uint32_t& tota, uint32_t& totb)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t ia = a, ib = b;
-#pragma unroll
-    for(int o = 1; o < 64; o <<= 1)
-    {
-        const uint32_t ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
-        if(lane >= o)
-        {
-            ia += ta;
-            ib += tb;
-        }
-    }
+    const uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b);
     if(lane == 63)
     {
         s.wsum[wave] = ia;
