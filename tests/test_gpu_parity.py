@@ -275,3 +275,30 @@ def test_sparse_corners_use_fallback_threshold(pkg, orc):
     assert len(ref["xy"]) > 10 and ref["response"].min() < 20 <= ref["response"].max()
     assert_same_detection(got, ref)
     c.close()
+
+
+def test_stage_timing_modes_do_not_change_results(pkg, orc, synth_frames):
+    """mode 1 serialises every stage on one stream (and takes the plain, non-graph single-frame path), mode 2 times
+    every launch in place; both must leave the results untouched and report the stages by name"""
+    import torch
+    ref = orc.detect(synth_frames[0], orc.params())
+    c = pkg.Context(width=640, height=480, max_batch=16)
+    for mode in (1, 2, 0):
+        c.set_profiling(mode)
+        assert_same_detection(c.detect(synth_frames[0]), ref)
+    dev = torch.from_numpy(np.stack([synth_frames[i % 6] for i in range(16)])).cuda()
+    expected = {"gray", "resize", "fast", "quadtree", "blur", "describe", "match_knn2", "ratio_compact"}
+    for mode in (1, 2):
+        c.set_profiling(mode)
+        c.detect_batch_dev(dev.data_ptr(), 16)   # 16 frames: two chunks on two streams in mode 2
+        c.match_batch_dev(0.7, False)
+        c.sync()
+        times = c.stage_times()
+        assert {n for n, _ in times} == expected and all(ms > 0 for _, ms in times)
+        v = c.batch_view()
+        cnt = pkg.read_device(c, v.count, (16,), np.int32)
+        desc = pkg.read_device(c, v.desc, (16, v.capacity, 32), np.uint8)
+        assert cnt[0] == len(ref["xy"]) and np.array_equal(desc[0, :cnt[0]], ref["desc"])
+        assert cnt[6] == cnt[0] and np.array_equal(desc[6, :cnt[6]], ref["desc"])
+    c.set_profiling(0)
+    c.close()
