@@ -151,8 +151,10 @@ def main():
     d_frames = torch.from_numpy(frames).cuda()
     frame_bytes = a.width * a.height * 3
 
-    ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, max_keypoints=4096, max_candidates=16384,
-                      device=dev)
+    # capacities scale with the frame area (4096 keypoints / 16384 FAST candidates per level at 640x480)
+    area = max(1, -(-a.width * a.height // (640 * 480)))
+    ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, max_keypoints=4096 * area,
+                      max_candidates=16384 * area, device=dev)
     n_batches = n_unique // B
     cross = None
     if a.bow:
