@@ -302,3 +302,24 @@ def test_stage_timing_modes_do_not_change_results(pkg, orc, synth_frames):
         assert cnt[6] == cnt[0] and np.array_equal(desc[6, :cnt[6]], ref["desc"])
     c.set_profiling(0)
     c.close()
+
+
+def test_cfg5_full_hd_three_levels(pkg, orc):
+    """BASELINE cfg5: 1920x1080, 3 levels, ~15 k keypoints per frame, detect + ratio-test match of two frames
+    (the level-0 quadtree runs in its global-memory form, the matcher on 15 k x 15 k pairs)"""
+    import synth
+    frames = synth.make_stream(2, 1920, 1080, seed=4321)
+    c = pkg.Context(width=1920, height=1080, n_levels=3, min_node_area=150, max_keypoints=32768, max_candidates=131072)
+    p = orc.params(n_levels=3, min_size=150)
+    dets, refs = [], []
+    for f in frames:
+        got = c.detect(f, max_out=32768)
+        ref = orc.detect(f, p)
+        assert_same_detection(got, ref)
+        dets.append(got)
+        refs.append(ref)
+    assert len(refs[0]["xy"]) > 10000
+    gf, gt = c.match(dets[1]["desc"], dets[0]["desc"])
+    rf, rt = orc.match(refs[1]["desc"], refs[0]["desc"])
+    assert len(rf) > 1000 and np.array_equal(gf, rf) and np.array_equal(gt, rt)
+    c.close()
