@@ -36,6 +36,8 @@ MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4
 STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "mslam::k_resize_col", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur", "describe": "mslam::k_describe",
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact"}
+if os.environ.get("MSLAM_HIP_MATCHER") == "popcount":  # the xor/popcount matcher instead of the matrix-core one
+    STAGE_KERNEL["match_knn2"] = "void mslam::k_match_knn2<8, 1, 8>"
 
 
 def pmc_traffic(stage, kernels_per_launch, frames_per_launch):
@@ -54,6 +56,14 @@ def pmc_traffic(stage, kernels_per_launch, frames_per_launch):
     except (OSError, KeyError, ValueError):
         return None
     return int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024 * scale * kernels_per_launch)
+
+
+def baseline_metric():
+    """the metric string of BASELINE.json (this file sits next to it)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except (OSError, KeyError, ValueError):
+        return "ORB keypoints extracted+matched /sec, 640\u00d7480 RGB-D, 1/2/4/8 GPU; HBM GB/s vs roofline"
 
 
 def parse():
@@ -255,23 +265,33 @@ def main():
             ctx.set_profiling(0)
             roofline["stages_ms_serialized"] = {k: round(x, 4) for k, x in ser.items()}
         if "match_knn2" in acc:
-            # the matcher is not HBM-bound.  Its distances run on the matrix cores as FP4 +-1 dot
-            # products (2*256 flop per pair, dense FP4 peak ~10 PFLOP/s); its top-2 selection is one v_med3 + one
-            # v_max per pair on the VALU (34 lane-ops per 16 pairs), which is the pipe that bounds it.
+            # the matcher is not HBM-bound
             pairs = B * (kp_b / B) ** 2
             t_s = avg["match_knn2"] * 1e-3
-            roofline["match_mfma"] = {"bound": "mfma", "dtype": "fp4 (+-1, exact)", "pairs_per_launch": int(pairs),
-                                      "achieved": round(pairs * 512 / t_s / 1e12, 1), "peak": MFMA_FP4_PEAK_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": round(pairs * 512 / t_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)}
-            tops = pairs * (34 / 16) / t_s / 1e12
-            roofline["match_valu"] = {"bound": "valu-issue", "ops_per_pair": 34 / 16, "achieved": round(tops, 2),
-                                      "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
-                                      "frac": round(tops / VALU_PEAK_TOPS, 3)}
+            roofline["match_kernel"] = STAGE_KERNEL["match_knn2"]
+            if os.environ.get("MSLAM_HIP_MATCHER") == "popcount":
+                # xor/popcount form: 8 xor + 8 bcnt + 3 top-2 lane-ops per pair on the integer VALU
+                tops = pairs * 19 / t_s / 1e12
+                roofline["match_valu"] = {"bound": "int-valu", "pairs_per_launch": int(pairs), "ops_per_pair": 19,
+                                          "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2),
+                                          "unit": "Tlane-op/s", "frac": round(tops / VALU_PEAK_TOPS, 3)}
+            else:
+                # distances on the matrix cores as FP4 +-1 dot products (2*256 flop per pair, dense FP4 peak ~10
+                # PFLOP/s); the top-2 selection is one v_med3 + one v_max per pair on the VALU (34 lane-ops per 16
+                # pairs), which is the pipe that bounds it
+                roofline["match_mfma"] = {"bound": "mfma", "dtype": "fp4 (+-1, exact)", "pairs_per_launch": int(pairs),
+                                          "achieved": round(pairs * 512 / t_s / 1e12, 1), "peak": MFMA_FP4_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s",
+                                          "frac": round(pairs * 512 / t_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)}
+                tops = pairs * (34 / 16) / t_s / 1e12
+                roofline["match_valu"] = {"bound": "valu-issue", "ops_per_pair": 34 / 16, "achieved": round(tops, 2),
+                                          "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
+                                          "frac": round(tops / VALU_PEAK_TOPS, 3)}
         w, h, _ = ctx.level_geometry()
         P = sum(x * y for x, y in zip(w, h))
         extract_bytes = 3 * a.width * a.height + 2 * P + 48 * (kp_b / B)
         out = {
-            "metric": "ORB keypoints extracted+matched /sec, 640x480 RGB-D", "value": kp_total / dt_max,
+            "metric": baseline_metric(), "value": kp_total / dt_max,
             "unit": "keypoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
