@@ -109,6 +109,17 @@ int mslam_hip_match_knn2(mslam_hip_ctx* ctx, const uint8_t* from_desc, int n_fro
  * to = frame t-1); frame 0 is matched against the last frame of the previous batch when
  * `chain_previous` is non-zero and one exists.  Results: mslam_hip_batch_view.match_*. */
 int mslam_hip_match_batch_dev(mslam_hip_ctx* ctx, double ratio, int chain_previous);
+/* Which kernel computes the 256-bit Hamming distances (results are identical, tests run both):
+ * AUTO = matrix cores (bits as FP4 +-1, exact) up to 32736 train rows and xor/popcount beyond; POPCOUNT = the
+ * xor/__popc form BASELINE.json's north_star names, always.  The initial value comes from the environment
+ * variable MSLAM_HIP_MATCHER ("popcount") read at mslam_hip_create. */
+enum
+{
+    MSLAM_HIP_MATCHER_AUTO = 0,
+    MSLAM_HIP_MATCHER_POPCOUNT = 1
+};
+int mslam_hip_set_matcher(mslam_hip_ctx* ctx, int kind);
+int mslam_hip_get_matcher(const mslam_hip_ctx* ctx);
 
 /* ---- IRelocalizer / ILoopDetector: DBoW3 bag of words ---------------------------------------------
  * Replaces what OrbRelocalizer is wired for (orb_relocalizer.cpp:26-50, relocalizer.hpp:11-20,

@@ -25,8 +25,9 @@ LIB_PATH = os.path.join(_HERE, "libmslam_hip.so")
 
 OK, E_INVALID, E_RUNTIME, E_CAPACITY, E_NO_VOCABULARY, E_FORMAT = range(6)
 DBG_PYRAMID, DBG_BLURRED, DBG_CANDIDATES, DBG_SELECTED = range(4)
+MATCHER_AUTO, MATCHER_POPCOUNT = 0, 1
 
-# every symbol include/mslam_hip.h declares (tests/test_cabi_symbols.py checks the .so exports them all)
+# every symbol include/mslam_hip.h declares (tests/test_cabi.py checks the .so exports them all)
 ABI_SYMBOLS = [
     "mslam_hip_default_params", "mslam_hip_abi_version", "mslam_hip_create", "mslam_hip_destroy",
     "mslam_hip_last_error", "mslam_hip_sync", "mslam_hip_detect", "mslam_hip_detect_batch_dev",
@@ -35,7 +36,7 @@ ABI_SYMBOLS = [
     "mslam_hip_bow_score", "mslam_hip_bow_db_add", "mslam_hip_bow_db_query", "mslam_hip_bow_db_clear",
     "mslam_hip_bow_batch_dev", "mslam_hip_get_bow_view", "mslam_hip_bow_cross_score_dev", "mslam_hip_level_geometry", "mslam_hip_debug_read",
     "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host", "mslam_hip_backproject", "mslam_hip_backproject_batch_dev",
-    "mslam_hip_get_points_view",
+    "mslam_hip_get_points_view", "mslam_hip_set_matcher", "mslam_hip_get_matcher",
 ]
 
 
@@ -182,6 +183,13 @@ class Context:
         self._chk(self.L.mslam_hip_match(self._h, _p(f), len(f), _p(t), len(t), C.c_double(ratio), _p(fi), _p(ti),
                                          C.byref(n)))
         return fi[:n.value].copy(), ti[:n.value].copy()
+
+    def set_matcher(self, kind):
+        """MATCHER_AUTO (matrix cores up to 32736 train rows) or MATCHER_POPCOUNT (xor/popcount always)."""
+        self._chk(self.L.mslam_hip_set_matcher(self._h, int(kind)))
+
+    def get_matcher(self):
+        return self.L.mslam_hip_get_matcher(self._h)
 
     def match_knn2(self, from_desc, to_desc):
         f = np.ascontiguousarray(from_desc, np.uint8).reshape(-1, 32)

@@ -529,6 +529,8 @@ static int create_impl(mslam_hip_ctx* c)
     {
         const char* e = getenv("MSLAM_HIP_OVERLAP_MATCH");
         c->overlap_match = !(e && atoi(e) == 0);
+        const char* m = getenv("MSLAM_HIP_MATCHER");
+        c->matcher_kind = (m && std::strcmp(m, "popcount") == 0) ? MSLAM_HIP_MATCHER_POPCOUNT : MSLAM_HIP_MATCHER_AUTO;
     }
     select_set(c, 0);
     HIPCHK(c, hipDeviceSynchronize());
@@ -892,6 +894,7 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
         m.to_cnt = c->d_count + first;
         m.cap = c->p.max_keypoints;
         m.cap_from = c->p.max_keypoints;
+        m.popcount_only = c->matcher_kind == MSLAM_HIP_MATCHER_POPCOUNT;
         m.idx0 = c->d_idx0 + (size_t)first * K;
         m.idx1 = c->d_idx1 + (size_t)first * K;
         m.dist0 = c->d_dist0 + (size_t)first * K;
@@ -968,7 +971,20 @@ static void host_match_args(mslam_hip_ctx* c, int n_from, int n_to, MatchArgs& m
     m.idx1 = c->d_hm_out + cap;
     m.dist0 = c->d_hm_out + 2 * cap;
     m.dist1 = c->d_hm_out + 3 * cap;
+    m.popcount_only = c->matcher_kind == MSLAM_HIP_MATCHER_POPCOUNT;
 }
+
+int mslam_hip_set_matcher(mslam_hip_ctx* c, int kind)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(kind != MSLAM_HIP_MATCHER_AUTO && kind != MSLAM_HIP_MATCHER_POPCOUNT)
+        return fail(c, MSLAM_HIP_E_INVALID, "set_matcher: unknown kind");
+    c->matcher_kind = kind;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_get_matcher(const mslam_hip_ctx* c) { return c ? c->matcher_kind : -1; }
 
 int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,
                          int32_t* idx0, int32_t* idx1, int32_t* dist0, int32_t* dist1)

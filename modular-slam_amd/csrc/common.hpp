@@ -146,6 +146,7 @@ struct MatchArgs
     int32_t* dist0;
     int32_t* dist1;
     int cap_from = 0;                 // upper bound of from_cnt[] (per-pair capacity of the train side)
+    int popcount_only = 0;            // 1: the xor/popcount kernel whatever the train size (mslam_hip_set_matcher)
     int n_pairs = 0, wg_per_pair = 0; // filled in by the launcher
 };
 void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s);

@@ -78,6 +78,7 @@ struct mslam_hip_ctx
     int cur = 0;
     hipStream_t stream_m = nullptr; // matcher stream
     bool overlap_match = true;
+    int matcher_kind = 0; // MSLAM_HIP_MATCHER_*
     // outputs: slot 0 = last frame of the previous batch, slots 1..max_batch = current batch
     float* d_xy = nullptr;
     uint8_t* d_desc = nullptr;

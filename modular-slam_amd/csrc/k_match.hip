@@ -388,14 +388,11 @@ void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
     // matrix-core kernel (4 query tiles per wave: 0.117 ms per 250 x 1900^2 pairs against 0.48 ms for the
     // VALU kernel) whenever the train side fits its 14-bit age field; the VALU kernel otherwise
     // (8 waves x 1 query per lane, 8 rows per scalar-load batch: the fastest of its variants).
-    // MSLAM_HIP_MATCHER=popcount selects the xor/popcount kernel everywhere (the form BASELINE.json's north_star
-    // describes; same results, 0.48 instead of 0.12 ms per 250 x 1900^2 pairs)
-    static const bool popcount_only = [] {
-        const char* e = getenv("MSLAM_HIP_MATCHER");
-        return e && std::strcmp(e, "popcount") == 0;
-    }();
+    // a.popcount_only (mslam_hip_set_matcher / MSLAM_HIP_MATCHER=popcount at context creation) selects the
+    // xor/popcount kernel everywhere (the form BASELINE.json's north_star describes; same results, 0.48 instead of
+    // 0.12 ms per 250 x 1900^2 pairs)
     const int max_train = a.from_cnt ? a.cap_from : a.n_from_fixed;
-    if(max_train <= MM_MAX_TRAIN && !popcount_only)
+    if(max_train <= MM_MAX_TRAIN && !a.popcount_only)
         return launch_fp4<4>(a, n_pairs, s);
     launch_variant<8, 1, 8>(a, n_pairs, s);
 }

@@ -142,3 +142,106 @@ def test_cross_stream_scores(pkg, orc, synth_frames):
             assert out[t, r] == orc.bow_score_l1(*vecs[t], *vecs[i])
     assert CrossStreamLoopCandidates.candidates(out, rank=-1, min_score=0.0)
     c.close()
+
+
+def _l1_model_best(orc, vecs, t, window=64):
+    """what the database must report for entry t queried before it is added: the best of the last `window`
+    entries, ties to the lower entry id, entries without a common word absent"""
+    best = None
+    for e in range(max(0, t - window), t):
+        s = orc.bow_score_l1(*vecs[t], *vecs[e])
+        if s > 0 and (best is None or s > best[0]):
+            best = (s, e)
+    return best
+
+
+def test_cfg3_million_word_vocabulary(pkg, orc, descs):
+    """BASELINE cfg3: the k=10, L=6 vocabulary (1 111 111 nodes, 10^6 words, 35.6 MB of node descriptors: the last
+    two tree levels stream from HBM / Infinity Cache) — words, idf weights, BoW vectors (f64 bit patterns) and L1
+    scores against the oracle, for detected and random descriptors, through the host and the batched entry points."""
+    import torch
+    blob = synth.make_vocabulary(10, 6, seed=77)
+    V = orc.Vocabulary(blob)
+    assert (V.k, V.L, V.n_nodes, V.n_words) == (10, 6, 1111111, 1000000)
+    K = 4096
+    c = pkg.Context(width=640, height=480, max_batch=4, max_keypoints=K)
+    c.bow_load(blob)
+    info = c.bow_info()
+    assert (info["k"], info["L"], info["n_nodes"], info["n_words"]) == (10, 6, 1111111, 1000000)
+    rng = np.random.default_rng(9)
+    vecs = []
+    for d in (descs[0], descs[1], descs[2], rng.integers(0, 256, (4000, 32), dtype=np.uint8)):
+        gw, gwt = c.bow_words(d)
+        rw, rwt = V.words(d)
+        assert np.array_equal(gw, rw) and np.array_equal(gwt, rwt)
+        assert len(np.unique(rw)) > 0.9 * len(rw) and rw.max() > 900000      # the deep levels are really used
+        gv, rv = c.bow_transform(d), V.bow_vector(d)
+        assert np.array_equal(gv[0], rv[0]) and np.array_equal(gv[1], rv[1])
+        vecs.append(rv)
+    for i in range(4):
+        for j in range(4):
+            assert c.bow_score(*vecs[i], *vecs[j]) == orc.bow_score_l1(*vecs[i], *vecs[j])
+    # batched device path on the same vocabulary: vectors, best entry and score per frame (query-then-add)
+    frames = synth.make_stream(4, 640, 480, seed=1234)
+    c.detect_batch_dev(torch.from_numpy(frames).cuda().data_ptr(), 4)
+    c.bow_batch_dev(True)
+    c.sync()
+    v = c.bow_view()
+    n = pkg.read_device(c, v.n_words, (4,), np.int32)
+    words = pkg.read_device(c, v.words, (4, K), np.uint32)
+    vals = pkg.read_device(c, v.values, (4, K), np.float64)
+    be = pkg.read_device(c, v.best_entry, (4,), np.int32)
+    bs = pkg.read_device(c, v.best_score, (4,), np.float64)
+    fv = [V.bow_vector(orc.detect(f, orc.params())["desc"]) for f in frames]
+    for t in range(4):
+        assert n[t] == len(fv[t][0])
+        assert np.array_equal(words[t, :n[t]], fv[t][0]) and np.array_equal(vals[t, :n[t]], fv[t][1])
+        exp = _l1_model_best(orc, fv, t)
+        assert (be[t], bs[t]) == ((exp[1], exp[0]) if exp else (-1, 0.0))
+    c.close()
+
+
+def test_database_window_wraps(pkg, orc):
+    """the database keeps the most recent entries in a ring: 150 host-side adds and 50 batches of 3 frames wrap the
+    ring more than twice; every query must equal the oracle's model of "the last 64 entries"."""
+    import torch
+    blob = synth.make_vocabulary(10, 3)
+    V = orc.Vocabulary(blob)
+    K = 4096
+    c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=K)
+    c.bow_load(blob)
+    rng = np.random.default_rng(21)
+    pool = rng.integers(0, 256, (40, 300, 32), dtype=np.uint8)      # 40 descriptor sets that share words
+    sets, vecs = [], []
+    for t in range(150):
+        d = pool[rng.integers(0, 40)].copy()
+        d[:rng.integers(1, 200)] = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+        sets.append(d)
+        vecs.append(V.bow_vector(d))
+    for t in range(150):
+        if t % 7 == 0 or t > 140:
+            ids, sc = c.bow_db_query(sets[t], 64)
+            exp = sorted(((orc.bow_score_l1(*vecs[t], *vecs[e]), e) for e in range(max(0, t - 64), t)),
+                         key=lambda x: (-x[0], x[1]))
+            exp = [x for x in exp if x[0] > 0]
+            assert list(ids) == [e for _, e in exp] and list(sc) == [s for s, _ in exp], t
+        assert c.bow_db_add(sets[t]) == t
+    c.bow_db_clear()
+    # batched path: frames cycle with period 5 (not a divisor of the batch size), so equal scores occur inside the
+    # window and the tie rule (lower entry id) is exercised across the wrap
+    frames = synth.make_stream(5, 640, 480, seed=1234)
+    fv5 = [V.bow_vector(orc.detect(f, orc.params())["desc"]) for f in frames]
+    order = [(7 * i) % 5 if i % 11 else (i // 11) % 5 for i in range(150)]
+    fv = [fv5[i] for i in order]
+    dev = torch.from_numpy(np.ascontiguousarray(frames[order])).cuda()
+    for b in range(50):
+        c.detect_batch_dev(dev[3 * b:].data_ptr(), 3)
+        c.bow_batch_dev(True)
+        c.sync()
+        v = c.bow_view()
+        be = pkg.read_device(c, v.best_entry, (3,), np.int32)
+        bs = pkg.read_device(c, v.best_score, (3,), np.float64)
+        for i in range(3):
+            exp = _l1_model_best(orc, fv, 3 * b + i)
+            assert (be[i], bs[i]) == ((exp[1], exp[0]) if exp else (-1, 0.0)), (b, i)
+    c.close()

@@ -92,7 +92,18 @@ def test_capacity_is_loud(pkg, synth_frames):
     c.close()
 
 
-def test_match_knn2_random(orc, ctx):
+@pytest.fixture(params=["matrix", "popcount"])
+def mctx(request, pkg, ctx):
+    """the shared context with the matcher form selected: the matrix-core kernel (default) or the xor/popcount
+    kernel north_star names (mslam_hip_set_matcher) — identical results are required of both"""
+    ctx.set_matcher(pkg.MATCHER_POPCOUNT if request.param == "popcount" else pkg.MATCHER_AUTO)
+    assert ctx.get_matcher() == (1 if request.param == "popcount" else 0)
+    yield ctx
+    ctx.set_matcher(pkg.MATCHER_AUTO)
+
+
+def test_match_knn2_random(orc, mctx):
+    ctx = mctx
     rng = np.random.default_rng(1)
     # (33000, 70): beyond the matrix-core kernel's train range -> the xor/popcount kernel; (17000, 130): 532 tiles
     for n_from, n_to in [(2000, 2000), (513, 257), (1, 5), (2, 3), (300, 1), (32, 64), (33, 600), (17000, 130),
@@ -105,8 +116,9 @@ def test_match_knn2_random(orc, ctx):
             assert np.array_equal(g, r)
 
 
-def test_match_ties_and_ratio(orc, ctx):
+def test_match_ties_and_ratio(orc, mctx):
     """few distinct descriptors => many equal distances: the lower train index must rank first."""
+    ctx = mctx
     rng = np.random.default_rng(2)
     base = rng.integers(0, 256, (7, 32), dtype=np.uint8)
     f = base[rng.integers(0, 7, 700)]
@@ -120,7 +132,8 @@ def test_match_ties_and_ratio(orc, ctx):
         assert np.array_equal(gf, rf) and np.array_equal(gt, rt)
 
 
-def test_match_detected_frames(orc, ctx, bundled_frames):
+def test_match_detected_frames(orc, mctx, bundled_frames):
+    ctx = mctx
     a = orc.detect(bundled_frames[0], orc.params())
     b = orc.detect(bundled_frames[1], orc.params())
     gf, gt = ctx.match(b["desc"], a["desc"])
@@ -129,19 +142,22 @@ def test_match_detected_frames(orc, ctx, bundled_frames):
     assert np.array_equal(gf, rf) and np.array_equal(gt, rt)
 
 
-def test_match_degenerate(ctx):
+def test_match_degenerate(mctx):
+    ctx = mctx
     d = np.zeros((5, 32), np.uint8)
     assert len(ctx.match(d[:1], d)[0]) == 0      # n_from < 2: reference UB, defined as no matches
     assert len(ctx.match(d, d[:0])[0]) == 0      # empty query set
     assert len(ctx.match(d[:0], d)[0]) == 0
 
 
-def test_batch_device_path(pkg, orc, synth_frames):
+@pytest.mark.parametrize("matcher", [0, 1])
+def test_batch_device_path(pkg, orc, synth_frames, matcher):
     """detect_batch_dev + match_batch_dev on HBM-resident frames, including the chain across batches."""
     import torch
     frames = synth_frames[:6]
     dev = torch.from_numpy(frames).cuda()
     c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=4096)
+    c.set_matcher(matcher)
     refs = [orc.detect(f, orc.params()) for f in frames]
     K = 4096
     for b in range(2):
@@ -319,7 +335,57 @@ def test_cfg5_full_hd_three_levels(pkg, orc):
         dets.append(got)
         refs.append(ref)
     assert len(refs[0]["xy"]) > 10000
-    gf, gt = c.match(dets[1]["desc"], dets[0]["desc"])
     rf, rt = orc.match(refs[1]["desc"], refs[0]["desc"])
-    assert len(rf) > 1000 and np.array_equal(gf, rf) and np.array_equal(gt, rt)
+    for matcher in (pkg.MATCHER_AUTO, pkg.MATCHER_POPCOUNT):
+        c.set_matcher(matcher)
+        gf, gt = c.match(dets[1]["desc"], dets[0]["desc"])
+        assert len(rf) > 1000 and np.array_equal(gf, rf) and np.array_equal(gt, rt)
+    c.close()
+
+
+def test_bench_launch_shape_1000_frames(pkg, orc, synth_frames):
+    """the launch shape bench.py times: ONE 1000-frame batch (two 500-frame chunks on two streams, ~2 GB of pyramid
+    slabs, 32-bit offsets at their largest), chained to a second batch.  Size-independent properties as in the
+    250-frame test, plus oracle spot checks at both chunk boundaries and the ends."""
+    import torch
+    B, K = 1000, 4096
+    idx = np.arange(B) % 6
+    idx[[499, 500, 501]] = [2, 2, 5]             # identical consecutive frames across the chunk boundary (499 | 500)
+    frames = torch.from_numpy(np.ascontiguousarray(synth_frames[idx])).cuda()
+    c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K)
+    refs = [orc.detect(f, orc.params()) for f in synth_frames[:6]]
+    for rep in range(2):
+        c.detect_batch_dev(frames.data_ptr(), B)
+        c.match_batch_dev(0.7, True)
+        c.sync()
+        v = c.batch_view()
+        cnt = pkg.read_device(c, v.count, (B,), np.int32)
+        desc = pkg.read_device(c, v.desc, (B, K, 32), np.uint8)
+        xy = pkg.read_device(c, v.xy, (B, K, 2), np.float32)
+        ang = pkg.read_device(c, v.angle, (B, K), np.float32)
+        mc = pkg.read_device(c, v.match_count, (B,), np.int32)
+        mf = pkg.read_device(c, v.match_from, (B, K), np.int32)
+        mt = pkg.read_device(c, v.match_to, (B, K), np.int32)
+        for r in range(6):                       # every frame equals the oracle's result for its source frame
+            n = len(refs[r]["xy"])
+            sel = np.nonzero(idx == r)[0]
+            assert (cnt[sel] == n).all()
+            assert (desc[sel, :n] == refs[r]["desc"][None]).all()
+            assert (xy[sel, :n] == refs[r]["xy"][None]).all()
+            assert (ang[sel, :n].view(np.uint32) == refs[r]["angle"].view(np.uint32)[None]).all()
+        # matches: pair (t, t-1) only depends on (idx[t], idx[t-1]); check one representative of every kind
+        # against the oracle and all others against their representative
+        seen = {}
+        for t in range(B):
+            prev = idx[t - 1] if t > 0 else (idx[B - 1] if rep == 1 else None)
+            if prev is None:
+                assert mc[t] == 0
+                continue
+            key = (idx[t], prev)
+            if key not in seen:
+                rf, rt = orc.match(refs[key[0]]["desc"], refs[key[1]]["desc"])
+                seen[key] = (rf, rt)
+            rf, rt = seen[key]
+            assert mc[t] == len(rf) and np.array_equal(mf[t, :mc[t]], rf) and np.array_equal(mt[t, :mc[t]], rt), t
+        assert (2, 2) in seen and np.array_equal(*seen[(2, 2)])   # identical predecessor: every match maps i -> i
     c.close()
