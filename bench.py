@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — ORB extract + BF-Hamming match throughput on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of HBM-resident synthetic frames:
-detect (gray -> pyramid -> FAST cells -> quadtree -> blur -> orientation + rBRIEF) followed by the
-knn-2 Hamming match of every frame against its predecessor (chained across batches), exactly the
-call order of RgbdFeatureFrontend (rgbd_feature_frontend.cpp:187,237).
+A "step" is one pass of the hot path over one batch of HBM-resident synthetic RGB-D frames:
+detect (gray -> pyramid -> FAST cells -> quadtree -> blur -> orientation + rBRIEF), the knn-2 Hamming
+match of every frame against its predecessor (chained across batches) — the call order of
+RgbdFeatureFrontend (rgbd_feature_frontend.cpp:187,237) — and the depth lookup + back-projection of the
+keypoints (rgbd_feature_frontend.cpp:101-138), the step that consumes the D of RGB-D.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run (one rank per GPU): every rank runs its own stream
-(seed 1234 + 100*rank), no data-path collective is needed for extract+match ("weak" scaling);
-timing is barrier + synchronize on both sides and the MAX over ranks.
+N > 1: one rank per GPU.  When started WITHOUT a torch.distributed environment, bench.py spawns the N
+ranks itself (a child `python -m torch.distributed.run ... bench.py <same arguments>`, before anything
+touches the GPU) and exits with the child's code; started by torch.distributed.run it reads RANK /
+LOCAL_RANK / WORLD_SIZE.  Every rank runs its own stream (seed 1234 + 100*rank); extract + match need no
+data-path collective ("weak" scaling); timing is barrier + synchronize on both sides and the MAX over
+ranks.  With N > 1 the loop-candidate exchange (DBoW3 vectors, ONE all-gather per batch over RCCL,
+cross-stream scoring) is exercised and timed after the headline region ("exchange"); `--bow` puts BoW
+scoring and the exchange inside the step (cfg3 / cfg4).
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the context's stream
-for the dominant kernel; `cpu_baseline` times the CPU oracle (oracle/, the restatement of the
-reference's CPU plugin) on a bounded sample of the same stream on the host cores.
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the launching stream for
+the dominant kernel; `cpu_baseline` times the CPU oracle (oracle/, the restatement of the reference's
+CPU plugin) on a bounded sample of the same stream on the host cores; `pcie_inclusive` is the same
+pipeline fed from pinned host memory (double-buffered H2D) with the results copied back (D2H).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,27 +45,57 @@ VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md, matrix cores)
 STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "mslam::k_resize_col", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur", "describe": "mslam::k_describe",
-                "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact"}
-if os.environ.get("MSLAM_HIP_MATCHER") == "popcount":  # the xor/popcount matcher instead of the matrix-core one
-    STAGE_KERNEL["match_knn2"] = "void mslam::k_match_knn2<8, 1, 8>"
+                "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
+                "backproject": "mslam::k_backproject"}
+POPCOUNT_KERNEL = "void mslam::k_match_knn2<8, 1, 8>"
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_launch.json")
+SQ_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_sq_per_launch.json")
 
 
-def pmc_traffic(stage, kernels_per_launch, frames_per_launch):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
-    collected in separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced
-    streaming reads — MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known
-    input confirms: 500 frames x 921 600 B = 460.8 MB, FETCH_SIZE reads 230.4 MB).  None when no profile
-    is committed.  `kernels_per_launch`: the resize stage is 7 kernels (one per level) timed as one."""
-    path = os.path.join(ROOT, "profiles", "r01_e_pmc_fetch_write_per_launch.json")
+def csrc_sha():
+    """fingerprint of the kernel sources: a committed PMC profile is only quoted for the sources it was taken on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "modular-slam_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, kernels_per_launch, frames_per_launch):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected in
+    separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced streaming reads —
+    MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known input confirms).  Returns
+    (bytes or None, note): None when no profile is committed or it was taken on other kernel sources."""
     try:
-        j = json.load(open(path))
-        k = STAGE_KERNEL[stage]
-        d = j[k]
+        j = json.load(open(PMC_PROFILE))
+        meta = j["_meta"]
+        d = j[kernel]
+        fpl = meta["frames_per_launch"]
+        scale = frames_per_launch / float(fpl.get(kernel, fpl["default"]))  # traffic is linear in the batch size
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC profile committed for this kernel (%s)" % os.path.basename(PMC_PROFILE)
+    if meta.get("csrc_sha") != csrc_sha():
+        return None, "stale: %s was collected on kernel sources %s, this build is %s" % (
+            os.path.basename(PMC_PROFILE), meta.get("csrc_sha"), csrc_sha())
+    return (int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024 * scale * kernels_per_launch),
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH + WRITE) KB per launch, %s" %
+            os.path.basename(PMC_PROFILE))
+
+
+def valu_fraction(kernel, avg_ms, frames_per_launch):
+    """vector-ALU issue time of the kernel / its duration, from the committed SQ pass (SQ_INSTS_VALU x 4 cycles over
+    1024 SIMDs at 2.4 GHz); None when not available for these sources"""
+    try:
+        j = json.load(open(SQ_PROFILE))
+        if j["_meta"].get("csrc_sha") != csrc_sha():
+            return None
         fpl = j["_meta"]["frames_per_launch"]
-        scale = frames_per_launch / float(fpl.get(k, fpl["default"]))  # traffic is linear in the batch size
+        scale = frames_per_launch / float(fpl.get(kernel, fpl["default"]))
+        insts = j[kernel]["SQ_INSTS_VALU"] * scale
     except (OSError, KeyError, ValueError):
         return None
-    return int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024 * scale * kernels_per_launch)
+    return insts * 4 / (1024 * 2.4e9) / (avg_ms * 1e-3)
 
 
 def baseline_metric():
@@ -63,7 +103,7 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except (OSError, KeyError, ValueError):
-        return "ORB keypoints extracted+matched /sec, 640\u00d7480 RGB-D, 1/2/4/8 GPU; HBM GB/s vs roofline"
+        return "ORB keypoints extracted+matched /sec, 640×480 RGB-D, 1/2/4/8 GPU; HBM GB/s vs roofline"
 
 
 def parse():
@@ -75,22 +115,36 @@ def parse():
     ap.add_argument("--unique", type=int, default=1000, help="distinct synthetic frames kept in HBM (cycled)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--levels", type=int, default=8)
+    ap.add_argument("--min-area", type=int, default=1000, help="quadtree stop area (reference default 1000)")
     ap.add_argument("--bow", action="store_true",
-                    help="cfg3/cfg4: also DBoW3 loop scoring every frame (synthetic k=10 vocabulary) and, with "
-                         "N>1, the RCCL all-gather of BoW vectors + cross-stream scoring")
+                    help="cfg3/cfg4: DBoW3 loop scoring every frame (synthetic k=10 vocabulary) inside the step and, "
+                         "with N>1, the RCCL all-gather of BoW vectors + cross-stream scoring")
     ap.add_argument("--voc-levels", type=int, default=6, help="vocabulary depth L (k=10): 6 -> 1e6 words")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU run) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serialized", action="store_true",
-                    help="also report every stage timed alone (all work on one stream), after the timed region")
-    ap.add_argument("--cpu-sample", type=int, default=500, help="frames of the stream timed on the CPU oracle")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs after the timed region (popcount matcher, serialized stages, PCIe-inclusive, "
+                         "exchange): what the profiling passes use")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """python bench.py --gpus N without a torch.distributed environment: start the N ranks as a child process
+    (never exec: under rocprofv3 this process may already have initialised the GPU) and return its exit code"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
-    """Algorithmic HBM bytes per LAUNCH for every stage: each input byte read once,
-    each output byte written once, for a batch of B frames with n_kp keypoints / n_cand FAST
-    candidates in total."""
+    """Algorithmic HBM bytes per STEP for every stage: each input byte read once, each output byte
+    written once, for a batch of B frames with n_kp keypoints / n_cand FAST candidates in total."""
     w, h, _ = ctx.level_geometry()
     px = [a * b for a, b in zip(w, h)]
     P = sum(px)
@@ -103,6 +157,7 @@ def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
         "describe": B * 2 * P + 48 * n_kp,  # reads both planes around each keypoint, writes desc+xy+angle+octave+resp
         "match_knn2": 2 * 32 * n_kp + 16 * n_kp,
         "ratio_compact": 12 * n_kp + 8 * n_kp,
+        "backproject": 8 * n_kp + 2 * n_kp + 25 * n_kp,
         # bow_tree = n*(32 + L*k*32) + n*12 out; vectors are <= n x (u32, f64)
         "bow_descend": n_kp * (32 + voc_L * voc_k * 32) + 12 * n_kp,
         "bow_vector": 12 * n_kp + 12 * n_kp,
@@ -110,35 +165,77 @@ def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
     }
 
 
-def cpu_baseline(frames, n_sample):
-    """Oracle (= port of the reference CPU plugin) detect + match on the host cores."""
+def cpu_baseline(frames, params_kw, seconds):
+    """Oracle (= port of the reference CPU plugin) detect + match on the host cores: one core, then all cores
+    (frames sharded over threads; the C oracle releases the GIL inside ctypes calls)."""
     import __graft_entry__ as graft
     from concurrent.futures import ThreadPoolExecutor
     orc = graft.load_oracle()
     orc.lib()
-    cores = max(1, min(os.cpu_count() or 1, 32))
-    n_sample = min(n_sample, len(frames))
-    p = orc.params()
-    sample = [np.ascontiguousarray(frames[i]) for i in range(n_sample)]
+    cores = os.cpu_count() or 1
+    p = orc.params(**params_kw)
 
-    # detect every frame once (parallel over frames), then match consecutive pairs (parallel over pairs):
+    def run(n, threads):
+        sample = [np.ascontiguousarray(frames[i % len(frames)]) for i in range(n)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            dets = list(ex.map(lambda i: orc.detect(sample[i], p), range(n)))
+            list(ex.map(lambda i: orc.match(dets[i]["desc"], dets[i - 1]["desc"]), range(1, n)))
+        dt = time.perf_counter() - t0
+        return sum(len(d["xy"]) for d in dets) / dt, dt
+
+    # size the samples from a short probe so that the leg stays within its budget on any host
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        dets = list(ex.map(lambda i: orc.detect(sample[i], p), range(n_sample)))
-        list(ex.map(lambda i: orc.match(dets[i]["desc"], dets[i - 1]["desc"]), range(1, n_sample)))
-    dt = time.perf_counter() - t0
-    n_kp = sum(len(d["xy"]) for d in dets)
-    return {"value": n_kp / dt, "unit": "keypoints/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same synthetic 640x480 stream, detect + knn-2 match vs previous frame, "
-                      "oracle/ C restatement (scalar; OpenCV's internal SIMD is not reproduced), %d threads over frames"
-                      % (n_sample, cores)}
+    d0 = orc.detect(np.ascontiguousarray(frames[0]), p)
+    orc.match(d0["desc"], d0["desc"])
+    per_frame = max(time.perf_counter() - t0, 1e-3)
+    n1 = int(max(4, min(len(frames), 0.3 * seconds / per_frame)))
+    v1, dt1 = run(n1, 1)
+    nall = int(max(2 * cores, min(len(frames), 0.7 * seconds / per_frame * cores)))
+    vall, dtall = run(nall, cores)
+    return {"value": vall, "unit": "keypoints/s", "cores": cores, "kind": "port",
+            "value_1core": v1, "host_cpu_count": os.cpu_count(),
+            "sample": "the same synthetic stream, detect + knn-2 match vs previous frame, oracle/ C restatement "
+                      "(scalar; OpenCV's internal SIMD is not reproduced): %d frames on %d threads (%.1f s), "
+                      "%d frames on 1 thread (%.1f s)" % (nall, cores, dtall, n1, dt1)}
+
+
+def dry_run(a, rank, world):
+    """launcher rehearsal without a GPU (MSLAM_BENCH_DRY=1, used by the CPU test of `--gpus N`): rendezvous, the
+    barrier + MAX/SUM reductions of the real run, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    k = torch.tensor([100.0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "dist": {"backend": "gloo" if world > 1 else None, "world_size": world,
+                                   "launched_by": os.environ.get("MSLAM_BENCH_LAUNCHER", "external")},
+                          "t_max": float(t.item()), "units": float(k.item())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        os.environ["MSLAM_BENCH_LAUNCHER"] = "bench.py"
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d\n" % (a.gpus, world))
+        sys.exit(2)
+    if os.environ.get("MSLAM_BENCH_DRY") == "1":
+        return dry_run(a, rank, world)
     import torch
     import torch.distributed as dist
     # rehearsal aid: MSLAM_BENCH_DEVICE pins every rank to one GPU (only meaningful with --dist-backend gloo)
@@ -154,32 +251,49 @@ def main():
     import synth
     import __graft_entry__ as graft
     pkg = graft.load_package()
+    from modular_slam_amd.multi_stream import CrossStreamLoopCandidates, view_as_tensor, set_dwords
 
     B = a.batch
     n_unique = max(B, (a.unique // B) * B)
     frames = synth.make_stream(n_unique, a.width, a.height, seed=1234 + 100 * rank)
     d_frames = torch.from_numpy(frames).cuda()
+    depth = synth.make_depth(1, a.width, a.height, seed=1234 + 100 * rank)[0]
+    # depth of frame t = the base depth map shifted like the texture (a cheap stand-in for a moving camera)
+    d_depth = torch.from_numpy(np.ascontiguousarray(
+        np.stack([np.roll(depth, (-(t % 48), -((2 * t) % 64)), (0, 1)) for t in range(n_unique)])).view(np.int16)).cuda()
     frame_bytes = a.width * a.height * 3
+    depth_bytes = a.width * a.height * 2
 
     # capacities scale with the frame area (4096 keypoints / 16384 FAST candidates per level at 640x480)
     area = max(1, -(-a.width * a.height // (640 * 480)))
-    ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, max_keypoints=4096 * area,
-                      max_candidates=16384 * area, device=dev)
+    k_scale = area * max(1, 1000 // max(a.min_area, 1))
+    ts = torch.cuda.Stream()  # the context's stream is a torch stream: torch copies / collectives order against it
+    ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=a.min_area,
+                      max_keypoints=min(65535, 4096 * k_scale), max_candidates=16384 * area, device=dev, stream=ts.cuda_stream)
     n_batches = n_unique // B
     cross = None
-    if a.bow:
+    need_voc = a.bow or (world > 1 and not a.no_extras)
+    if need_voc:
         ctx.bow_load(synth.make_vocabulary(10, a.voc_levels, seed=77))
-        from modular_slam_amd.multi_stream import CrossStreamLoopCandidates
-        cross = CrossStreamLoopCandidates(k_max=2048)
+        cross = CrossStreamLoopCandidates(k_max=2048 * k_scale)
 
-    def step(i):
+    def step(i, bow=a.bow):
         off = (i % n_batches) * B
         ctx.detect_batch_dev(d_frames.data_ptr() + off * frame_bytes, B)
         ctx.match_batch_dev(0.7, True)
-        if a.bow:
+        ctx.backproject_batch_dev(d_depth.data_ptr() + off * depth_bytes)
+        if bow:
             ctx.bow_batch_dev(True)
             if world > 1:
-                cross.step_gpu(ctx)
+                cross.step_gpu(ctx, ts, B)
+
+    def settle():
+        if cross is not None:
+            cross.finish(ts)
+        ctx.sync()  # also surfaces capacity overflows loudly
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
     # warm-up; the first pass over each distinct batch also counts its keypoints (the unit of the metric) and
     # FAST candidates, so that no extra launches are needed after the timed region
@@ -189,46 +303,166 @@ def main():
         ctx.sync()
         v = ctx.batch_view()  # the output set alternates between batches: fetch the view after every detect
         counts_per_batch[b] = int(pkg.read_device(ctx, v.count, (B,), np.int32).sum())
-        cand_per_batch[b] = sum(len(ctx.debug_keypoints(pkg.DBG_CANDIDATES, 0, l)) for l in range(8)) * B
+        cand_per_batch[b] = int(ctx.debug_counts(pkg.DBG_CANDIDATES, B).sum())
 
-    for i in range(max(a.warmup, n_batches)):
+    w_eff = max(a.warmup, n_batches)
+    for i in range(w_eff):
         step(i)
         if i % n_batches not in counts_per_batch:
             count_batch(i % n_batches)
-    ctx.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    w_eff_pre = max(a.warmup, n_batches)
-    ctx.set_profiling(2)  # HIP events around every stage, in place on the stream it is launched on, during the timed steps
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(w_eff_pre + i)
-    ctx.sync()  # also surfaces capacity overflows loudly
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    timed = ctx.stage_times(cap=8192)  # (stage, ms) of every launch of the timed steps
-    ctx.set_profiling(0)
+    settle()
+
+    def timed_run(first, profile):
+        if profile:
+            ctx.set_profiling(2)  # HIP events around every stage launch, in place on its stream
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(first + i)
+        settle()
+        dt = time.perf_counter() - t0
+        timed = ctx.stage_times(cap=8192) if profile else None  # (stage, ms) of every launch of the timed steps
+        if profile:
+            ctx.set_profiling(0)
+        t_max = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item()), timed
+
+    dt_max, timed = timed_run(w_eff, True)
 
     # units processed: keypoints extracted (and matched against the previous frame) in the timed steps
-    w_eff = max(a.warmup, n_batches)
     n_kp = sum(counts_per_batch[(w_eff + i) % n_batches] for i in range(a.steps))
-
-    t_max = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     kp_sum = torch.tensor([float(n_kp)], dtype=torch.float64, device=red_dev)
     if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(kp_sum, op=dist.ReduceOp.SUM)
-    dt_max, kp_total = float(t_max.item()), float(kp_sum.item())
+    kp_total = float(kp_sum.item())
+
+    # ---- after the timed region ---------------------------------------------------------------------------
+    extras = {}
+    if not a.no_extras:
+        # the same run with the xor/popcount matcher (the form north_star names): both values are always quoted
+        ctx.set_matcher(pkg.MATCHER_POPCOUNT)
+        for i in range(2):
+            step(i)
+        settle()
+        dt_pop, _ = timed_run(w_eff, False)
+        ctx.set_matcher(pkg.MATCHER_AUTO)
+        extras["value_popcount_matcher"] = kp_total / dt_pop
+        extras["ms_per_step_popcount_matcher"] = dt_pop / a.steps * 1e3
+
+        # every stage alone on the GPU (everything serialised on one stream)
+        ctx.set_profiling(1)
+        ser, reps = {}, 5
+        for i in range(reps):
+            step(i)
+            for name, ms in ctx.stage_times():
+                ser[name] = ser.get(name, 0.0) + ms / reps
+        ctx.set_profiling(0)
+        settle()
+        extras["stages_ms_serialized"] = {k: round(x, 4) for k, x in ser.items()}
+
+        if world > 1:
+            # the loop-candidate exchange: BoW vectors of the batch -> ONE all-gather -> cross-stream scores
+            n_ex = max(3, min(10, a.steps))
+            for i in range(2):
+                step(i, bow=False)
+                ctx.bow_batch_dev(True)
+                cross.step_gpu(ctx, ts, B)
+            settle()
+            c0 = cross.collectives
+            t0 = time.perf_counter()
+            for i in range(n_ex):
+                ctx.bow_batch_dev(True)
+                scores = cross.step_gpu(ctx, ts, B)
+            settle()
+            dt_ex = time.perf_counter() - t0
+            t_ex = torch.tensor([dt_ex], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t_ex, op=dist.ReduceOp.MAX)
+            s_host = scores.cpu().numpy()
+            extras["exchange"] = {
+                "what": "per batch: DBoW3 vectors of %d frames (k=10 L=%d vocabulary) -> pack -> ONE "
+                        "all_gather_into_tensor -> L1 scores of own frame t vs frame t of every stream" % (B, a.voc_levels),
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "collectives_per_batch": (cross.collectives - c0) / float(n_ex),
+                "bytes_per_rank_per_batch": 4 * set_dwords(B, cross.k_max),
+                "ms_per_batch_incl_bow": float(t_ex.item()) / n_ex * 1e3,
+                "self_score_min": float(s_host[:, rank].min()),
+                "cross_score_max": float(np.delete(s_host, rank, 1).max())}
+
+        if world == 1 and rank == 0:
+            # PCIe-inclusive: frames + depth start in pinned host memory, double-buffered H2D on a copy stream while
+            # the previous batch is processed; keypoints, descriptors, matches and 3-D points are copied back (D2H)
+            PB = min(250, B)
+            n_pb = 12
+            h_rgb = torch.from_numpy(frames[:PB]).pin_memory()
+            h_dep = torch.from_numpy(np.ascontiguousarray(d_depth[:PB].cpu().numpy())).pin_memory()
+            dbuf = [(torch.empty_like(h_rgb, device="cuda"), torch.empty_like(h_dep, device="cuda")) for _ in range(2)]
+            copy_stream = torch.cuda.Stream()
+            ev_in = [torch.cuda.Event() for _ in range(2)]
+            ev_free = [torch.cuda.Event() for _ in range(2)]
+            K = ctx.params.max_keypoints
+            host_out = {}
+
+            def results_to_host():
+                v, pv = ctx.batch_view(), ctx.points_view()
+                ctx.join_matcher()
+                with torch.cuda.stream(ts):
+                    for name, ptr, shape, dt in (("count", v.count, (PB,), torch.int32), ("xy", v.xy, (PB, K, 2), torch.float32),
+                                                 ("desc", v.desc, (PB, K, 32), torch.uint8),
+                                                 ("angle", v.angle, (PB, K), torch.float32),
+                                                 ("octave", v.octave, (PB, K), torch.int32),
+                                                 ("mfrom", v.match_from, (PB, K), torch.int32),
+                                                 ("mto", v.match_to, (PB, K), torch.int32),
+                                                 ("mcount", v.match_count, (PB,), torch.int32),
+                                                 ("xyz", pv.xyz, (PB, K, 3), torch.float64),
+                                                 ("valid", pv.valid, (PB, K), torch.uint8)):
+                        src = view_as_tensor(ptr, shape, dt)
+                        if name not in host_out:
+                            host_out[name] = torch.empty(shape, dtype=dt).pin_memory()
+                        host_out[name].copy_(src, non_blocking=True)
+
+            def h2d(i):
+                with torch.cuda.stream(copy_stream):
+                    if i >= 2:
+                        copy_stream.wait_event(ev_free[i % 2])  # the batch that used this buffer is done with it
+                    dbuf[i % 2][0].copy_(h_rgb, non_blocking=True)
+                    dbuf[i % 2][1].copy_(h_dep, non_blocking=True)
+                    ev_in[i % 2].record(copy_stream)
+
+            def run_pcie(n):
+                h2d(0)
+                for i in range(n):
+                    if i + 1 < n:
+                        h2d(i + 1)
+                    ts.wait_event(ev_in[i % 2])
+                    ctx.detect_batch_dev(dbuf[i % 2][0].data_ptr(), PB)
+                    ctx.match_batch_dev(0.7, True)
+                    ctx.backproject_batch_dev(dbuf[i % 2][1].view(torch.int16).data_ptr())
+                    ev_free[i % 2].record(ts)
+                    results_to_host()
+                settle()
+
+            run_pcie(2)
+            t0 = time.perf_counter()
+            run_pcie(n_pb)
+            dt_p = time.perf_counter() - t0
+            kp_p = int(host_out["count"].sum()) * n_pb
+            d2h = sum(t.numel() * t.element_size() for t in host_out.values())
+            extras["pcie_inclusive"] = {
+                "frames_per_s": n_pb * PB / dt_p, "keypoints_per_s": kp_p / dt_p,
+                "h2d_GBps": n_pb * (h_rgb.numel() + 2 * h_dep.numel()) / dt_p / 1e9, "d2h_GBps": n_pb * d2h / dt_p / 1e9,
+                "how": "%d batches of %d frames: RGB + depth from pinned host memory by double-buffered async H2D on a "
+                       "copy stream, overlapped with extract + match + back-projection of the previous batch; keypoints, "
+                       "descriptors, matches and 3-D points (capacity-strided arrays) copied back to pinned host memory; "
+                       "the headline `value` is the HBM-resident rate" % (n_pb, PB)}
 
     out = None
     if rank == 0:
-        # per-stage launch durations measured inside the timed region (HIP events on the launching stream)
-        # a step's entries end with its ratio_compact; a very long run stops recording at 8192 entries: keep whole steps
-        ends = [i for i, (name, _) in enumerate(timed) if name == "ratio_compact"]
-        steps_cov = len(ends)
+        # per-stage launch durations measured inside the timed region (HIP events on the launching stream);
+        # a step's entries end with its last stage; a very long run stops recording at 8192 entries: keep whole steps
+        last = "bow_score" if a.bow else "backproject"
+        ends = [i for i, (name, _) in enumerate(timed) if name == last]
+        steps_cov = max(len(ends), 1)
         timed = timed[:ends[-1] + 1] if ends else timed
         tot, cnt = {}, {}
         for name, ms in timed:
@@ -238,77 +472,83 @@ def main():
         per_step = {k: cnt[k] / float(steps_cov) for k in tot}       # launches per step (detector: one per chunk)
         acc = {k: tot[k] / steps_cov for k in tot}                   # ms per step, summed over the step's launches
         kp_b, cand_b = counts_per_batch[0], cand_per_batch[0]
-        sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)  # per step (B frames)
+        sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)   # per step (B frames)
         dom = max(acc, key=acc.get)
         fpl = B / per_step[dom]                                    # frames per launch of the dominant stage
         bytes_per_launch = sb[dom] / per_step[dom]
         achieved = bytes_per_launch / (avg[dom] * 1e-3) / 1e9
-        roofline = {"kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "bound": "hbm", "achieved": round(achieved, 1),
+        kern = STAGE_KERNEL.get(dom, dom)
+        traffic, traffic_note = pmc_traffic(kern, 7 if dom == "resize" else 1, fpl)
+        vfrac = valu_fraction(kern, avg[dom], fpl)
+        roofline = {"kernel": kern, "stage": dom, "bound": "hbm", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic(dom, 7 if dom == "resize" else 1, fpl),
+                    "traffic": traffic, "traffic_source": traffic_note,
+                    "limiter": ("vector-ALU issue: %.0f %% of the kernel's duration (SQ_INSTS_VALU, %s)" % (
+                        100 * vfrac, os.path.basename(SQ_PROFILE))) if vfrac is not None else
+                               "not HBM (see DESIGN.md §4: every stage but gray is issue- or latency-bound)",
                     "launches_per_step": per_step[dom], "frames_per_launch": fpl, "avg_ms": round(avg[dom], 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "timing": "HIP events on the launching stream around every stage launch of %d of the %d timed steps "
-                              "(%d launches of the dominant stage); the resize entry spans its 7 per-level kernels" % (
-                                  steps_cov, a.steps, cnt[dom]),
+                              "(%d launches of the dominant stage); chunks of a step run concurrently on two streams, so "
+                              "an in-place duration includes the sibling chunk's share of the GPU; the resize entry "
+                              "spans its per-level kernels" % (steps_cov, a.steps, cnt[dom]),
                     "stages_ms_per_launch": {k: round(x, 4) for k, x in avg.items()},
                     "stages_ms_per_step": {k: round(x, 4) for k, x in acc.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0 and k in sb}}
-        if a.serialized:
-            ctx.set_profiling(1)
-            ser = {}
-            reps = 5
-            for i in range(reps):
-                step(i)
-                for name, ms in ctx.stage_times():
-                    ser[name] = ser.get(name, 0.0) + ms / reps
-            ctx.set_profiling(0)
-            roofline["stages_ms_serialized"] = {k: round(x, 4) for k, x in ser.items()}
+        if "stages_ms_serialized" in extras:
+            roofline["stages_ms_serialized"] = extras.pop("stages_ms_serialized")
         if "match_knn2" in acc:
             # the matcher is not HBM-bound
             pairs = B * (kp_b / B) ** 2
             t_s = avg["match_knn2"] * 1e-3
             roofline["match_kernel"] = STAGE_KERNEL["match_knn2"]
-            if os.environ.get("MSLAM_HIP_MATCHER") == "popcount":
-                # xor/popcount form: 8 xor + 8 bcnt + 3 top-2 lane-ops per pair on the integer VALU
-                tops = pairs * 19 / t_s / 1e12
-                roofline["match_valu"] = {"bound": "int-valu", "pairs_per_launch": int(pairs), "ops_per_pair": 19,
-                                          "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2),
-                                          "unit": "Tlane-op/s", "frac": round(tops / VALU_PEAK_TOPS, 3)}
-            else:
-                # distances on the matrix cores as FP4 +-1 dot products (2*256 flop per pair, dense FP4 peak ~10
-                # PFLOP/s); the top-2 selection is one v_med3 + one v_max per pair on the VALU (34 lane-ops per 16
-                # pairs), which is the pipe that bounds it
-                roofline["match_mfma"] = {"bound": "mfma", "dtype": "fp4 (+-1, exact)", "pairs_per_launch": int(pairs),
-                                          "achieved": round(pairs * 512 / t_s / 1e12, 1), "peak": MFMA_FP4_PEAK_TFLOPS,
-                                          "unit": "TFLOP/s",
-                                          "frac": round(pairs * 512 / t_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)}
-                tops = pairs * (34 / 16) / t_s / 1e12
-                roofline["match_valu"] = {"bound": "valu-issue", "ops_per_pair": 34 / 16, "achieved": round(tops, 2),
-                                          "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
-                                          "frac": round(tops / VALU_PEAK_TOPS, 3)}
+            # distances on the matrix cores as FP4 +-1 dot products (2*256 flop per pair, dense FP4 peak ~10
+            # PFLOP/s); the top-2 selection is one v_med3 + one v_max per pair on the VALU (34 lane-ops per 16
+            # pairs), which is the pipe that bounds it
+            roofline["match_mfma"] = {"bound": "mfma", "dtype": "fp4 (+-1, exact)", "pairs_per_launch": int(pairs),
+                                      "achieved": round(pairs * 512 / t_s / 1e12, 1), "peak": MFMA_FP4_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s",
+                                      "frac": round(pairs * 512 / t_s / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)}
+            tops = pairs * (34 / 16) / t_s / 1e12
+            roofline["match_valu"] = {"bound": "valu-issue", "ops_per_pair": 34 / 16, "achieved": round(tops, 2),
+                                      "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
+                                      "frac": round(tops / VALU_PEAK_TOPS, 3)}
         w, h, _ = ctx.level_geometry()
         P = sum(x * y for x, y in zip(w, h))
         extract_bytes = 3 * a.width * a.height + 2 * P + 48 * (kp_b / B)
+        extract_gbs = extract_bytes * a.steps * B * world / dt_max / 1e9
+        roofline["extract_fused_ideal"] = {
+            "bytes_per_frame": int(extract_bytes), "achieved_GBps_per_gpu": round(extract_gbs / world, 1),
+            "frac": round(extract_gbs / world / HBM_PEAK_GBS, 4),
+            "what": "SURVEY.md §8d whole-extract figure 3WH + 2P + 48K per frame x frames/s of the whole step"}
+        cfg = "cfg2" if (a.width, a.height, a.levels) == (640, 480, 8) else "%dx%d, %d levels" % (a.width, a.height, a.levels)
         out = {
             "metric": baseline_metric(), "value": kp_total / dt_max,
             "unit": "keypoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "cfg2: synthetic %dx%d stream, 8-level ORB (reference defaults 1.2/20/7/min-area 1000), "
-                                   "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame%s" % (
-                           a.width, a.height, (" + DBoW3 k=10 L=%d loop scoring vs last 64 frames%s" % (
-                               a.voc_levels, " + RCCL all-gather of BoW vectors, cross-stream scores" if world > 1 else ""))
+            "config": {"workload": "%s: synthetic %dx%d RGB-D stream, %d-level ORB (reference defaults 1.2/20/7, min-area %d), "
+                                   "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame + depth back-projection%s" % (
+                           cfg, a.width, a.height, a.levels, a.min_area,
+                           (" + DBoW3 k=10 L=%d loop scoring vs last 64 frames%s" % (
+                               a.voc_levels, " + all-gather of BoW vectors, cross-stream scores" if world > 1 else ""))
                            if a.bow else ""),
                        "warmup_steps_run": w_eff,  # at least one per distinct batch: the warm-up also counts the keypoints
                        "frames_per_step": B, "frames_per_gpu": a.steps * B, "distinct_frames": n_unique,
                        "keypoints_per_frame": round(kp_b / B, 1), "fast_candidates_per_frame": round(cand_b / B, 1),
                        "frames_per_s": a.steps * B * world / dt_max,
-                       "extract_algorithmic_GBps_whole_job": extract_bytes * a.steps * B * world / dt_max / 1e9},
+                       "extract_algorithmic_GBps_whole_job": extract_gbs},
+            "match_kernel": STAGE_KERNEL["match_knn2"],
+            "dist": {"backend": dist.get_backend() if world > 1 else None,
+                     "world_size": dist.get_world_size() if world > 1 else 1,
+                     "launched_by": os.environ.get("MSLAM_BENCH_LAUNCHER", "external")},
             "roofline": roofline,
         }
+        if "value_popcount_matcher" in extras:
+            extras["popcount_match_kernel"] = POPCOUNT_KERNEL
+        out.update(extras)
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, a.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(frames, dict(n_levels=a.levels, min_size=a.min_area), a.cpu_seconds)
     ctx.close()
     if world > 1:
         dist.barrier()

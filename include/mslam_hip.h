@@ -109,6 +109,10 @@ int mslam_hip_match_knn2(mslam_hip_ctx* ctx, const uint8_t* from_desc, int n_fro
  * to = frame t-1); frame 0 is matched against the last frame of the previous batch when
  * `chain_previous` is non-zero and one exists.  Results: mslam_hip_batch_view.match_*. */
 int mslam_hip_match_batch_dev(mslam_hip_ctx* ctx, double ratio, int chain_previous);
+/* The batched matcher runs on a stream of its own behind the detect batch it reads.  This makes the context's
+ * stream wait (on the device, no host synchronisation) for every matcher launch enqueued so far, so that work the
+ * caller enqueues on the context's stream afterwards — e.g. an asynchronous copy of the match results — sees them. */
+int mslam_hip_join_matcher(mslam_hip_ctx* ctx);
 /* Which kernel computes the 256-bit Hamming distances (results are identical, tests run both):
  * AUTO = matrix cores (bits as FP4 +-1, exact) up to 32736 train rows and xor/popcount beyond; POPCOUNT = the
  * xor/__popc form BASELINE.json's north_star names, always.  The initial value comes from the environment
@@ -185,6 +189,19 @@ int mslam_hip_get_bow_view(mslam_hip_ctx* ctx, mslam_hip_bow_view* view);
 int mslam_hip_bow_cross_score_dev(mslam_hip_ctx* ctx, const uint32_t* d_words, const double* d_values,
                                   const int32_t* d_n, int n_sets, int capacity, double* d_scores);
 
+/* The exchange step itself, in the wire format of the all-gather (one "set" = one stream's batch):
+ *   uint2 {u32 word, f32 value} vec[n_frames][k_max]  (ascending words, zero padded), then int32 count[n_frames]
+ *   = n_frames * (2 * k_max + 1) dwords per set; k_max = 2048 gives the 16 KB per frame SURVEY.md §8e sizes.
+ * pack: the BoW vectors of the last mslam_hip_bow_batch_dev into d_out (device), on the context's stream; a vector
+ * with more than k_max words is reported by mslam_hip_sync as MSLAM_HIP_E_CAPACITY.
+ * cross_score_packed: d_sets = n_sets gathered sets; d_scores[t][r] (f64, [n_frames][n_sets]) = L1 score of frame t
+ * of set self_set against frame t of set r, on the f32 values as transmitted, summed in ascending word order.  It
+ * reads nothing but d_sets and may be enqueued on any stream (`stream` = hipStream_t, NULL = the context's): e.g.
+ * the communication stream right behind the collective, while the context's stream extracts the next batch. */
+int mslam_hip_bow_pack_dev(mslam_hip_ctx* ctx, int k_max, uint32_t* d_out);
+int mslam_hip_bow_cross_score_packed_dev(mslam_hip_ctx* ctx, const uint32_t* d_sets, int n_sets, int self_set,
+                                         int n_frames, int k_max, double* d_scores, void* stream);
+
 /* ---- RGB-D back-projection (the step after the matcher) ----------------------------
  * Replaces pointsFromRgbdKeypoints / reconstructPoint (rgbd_feature_frontend.cpp:101-138) with getDepth /
  * isDepthValid (types/depth_frame.hpp:20-30).  depth = DepthFrame::data (u16, row-major, width*height),
@@ -216,6 +233,9 @@ enum
 int mslam_hip_level_geometry(mslam_hip_ctx* ctx, int* widths, int* heights, float* scales);
 int mslam_hip_debug_read(mslam_hip_ctx* ctx, int what, int frame, int level, void* dst, size_t dst_bytes,
                          size_t* n_items);
+
+/* Per-(frame, level) counts of the last detect batch: out[n_frames][n_levels] (CANDIDATES or SELECTED). */
+int mslam_hip_debug_counts(mslam_hip_ctx* ctx, int what, int32_t* out);
 
 /* Synchronise the context's stream, then copy `bytes` from a device pointer (e.g. out of a view) to host memory. */
 int mslam_hip_copy_to_host(mslam_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);

@@ -37,6 +37,8 @@ ABI_SYMBOLS = [
     "mslam_hip_bow_batch_dev", "mslam_hip_get_bow_view", "mslam_hip_bow_cross_score_dev", "mslam_hip_level_geometry", "mslam_hip_debug_read",
     "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host", "mslam_hip_backproject", "mslam_hip_backproject_batch_dev",
     "mslam_hip_get_points_view", "mslam_hip_set_matcher", "mslam_hip_get_matcher",
+    "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
+    "mslam_hip_join_matcher",
 ]
 
 
@@ -184,6 +186,9 @@ class Context:
                                          C.byref(n)))
         return fi[:n.value].copy(), ti[:n.value].copy()
 
+    def join_matcher(self):
+        self._chk(self.L.mslam_hip_join_matcher(self._h))
+
     def set_matcher(self, kind):
         """MATCHER_AUTO (matrix cores up to 32736 train rows) or MATCHER_POPCOUNT (xor/popcount always)."""
         self._chk(self.L.mslam_hip_set_matcher(self._h, int(kind)))
@@ -281,6 +286,14 @@ class Context:
                                                        C.c_void_p(d_n), int(n_sets), int(capacity),
                                                        C.c_void_p(d_scores)))
 
+    def bow_pack_dev(self, k_max, d_out):
+        self._chk(self.L.mslam_hip_bow_pack_dev(self._h, int(k_max), C.c_void_p(d_out)))
+
+    def bow_cross_score_packed_dev(self, d_sets, n_sets, self_set, n_frames, k_max, d_scores, stream=None):
+        self._chk(self.L.mslam_hip_bow_cross_score_packed_dev(self._h, C.c_void_p(d_sets), int(n_sets), int(self_set),
+                                                              int(n_frames), int(k_max), C.c_void_p(d_scores),
+                                                              C.c_void_p(stream)))
+
     def bow_view(self):
         v = BowView()
         self._chk(self.L.mslam_hip_get_bow_view(self._h, C.byref(v)))
@@ -308,6 +321,12 @@ class Context:
         self._chk(self.L.mslam_hip_debug_read(self._h, what, frame, level, _p(out), C.c_size_t(out.nbytes),
                                               C.byref(n)))
         return out[:n.value].copy()
+
+    def debug_counts(self, what, n_frames):
+        """[n_frames, n_levels] FAST candidates (DBG_CANDIDATES) or selected keypoints (DBG_SELECTED) of the last batch"""
+        out = np.zeros((max(n_frames, 1), self.params.n_levels), np.int32)
+        self._chk(self.L.mslam_hip_debug_counts(self._h, int(what), _p(out)))
+        return out[:n_frames]
 
     def set_profiling(self, enable):
         """0 = off, 1/True = every stage, serialised on one stream, 2 = every stage launch, in place."""

@@ -576,6 +576,8 @@ static int check_flags(mslam_hip_ctx* c)
         m += " keypoints in a frame > max_keypoints;";
     if(f & kFlagQuadNoConverge)
         m += " quadtree pass limit;";
+    if(f & kFlagBowPackOverflow)
+        m += " a BoW vector has more words than the exchange format's k_max;";
     return fail(c, MSLAM_HIP_E_CAPACITY, m);
 }
 
@@ -974,6 +976,15 @@ static void host_match_args(mslam_hip_ctx* c, int n_from, int n_to, MatchArgs& m
     m.popcount_only = c->matcher_kind == MSLAM_HIP_MATCHER_POPCOUNT;
 }
 
+int mslam_hip_join_matcher(mslam_hip_ctx* c)
+{
+    ENTER(c);
+    for(auto& o : c->out)
+        if(o.match_pending)
+            HIPCHK(c, hipStreamWaitEvent(c->stream, o.ev_match, 0)); // stays pending: detect_prologue still orders on it
+    return MSLAM_HIP_OK;
+}
+
 int mslam_hip_set_matcher(mslam_hip_ctx* c, int kind)
 {
     if(!c)
@@ -1130,6 +1141,18 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
         return MSLAM_HIP_OK;
     }
     return fail(c, MSLAM_HIP_E_INVALID, "debug_read: unknown item");
+}
+
+int mslam_hip_debug_counts(mslam_hip_ctx* c, int what, int32_t* out)
+{
+    ENTER(c);
+    if(!out || (what != MSLAM_HIP_DBG_CANDIDATES && what != MSLAM_HIP_DBG_SELECTED))
+        return fail(c, MSLAM_HIP_E_INVALID, "debug_counts: bad argument");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the scratch arrays are indexed by the frame's position in the batch: [frame][level]
+    HIPCHK(c, hipMemcpy(out, what == MSLAM_HIP_DBG_CANDIDATES ? c->quad.cand_cnt : c->quad.sel_cnt,
+                        (size_t)std::max(c->n_last, 1) * c->geom.n_levels * 4, hipMemcpyDeviceToHost));
+    return MSLAM_HIP_OK;
 }
 
 int mslam_hip_copy_to_host(mslam_hip_ctx* c, void* dst_host, const void* src_dev, size_t bytes)

@@ -62,7 +62,8 @@ enum : uint32_t
 {
     kFlagCandOverflow = 1u,  // more FAST candidates on a level than max_candidates
     kFlagKpOverflow = 2u,    // more keypoints in a frame than max_keypoints
-    kFlagQuadNoConverge = 4u // quadtree pass limit hit (cannot happen for sane sizes)
+    kFlagQuadNoConverge = 4u, // quadtree pass limit hit (cannot happen for sane sizes)
+    kFlagBowPackOverflow = 8u // a BoW vector has more words than the exchange format's k_max
 };
 
 // ---- kernel launchers (each enqueues on `s`, no synchronisation) ----------------------------------

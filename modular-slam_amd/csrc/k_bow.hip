@@ -514,6 +514,98 @@ __global__ __launch_bounds__(64) void k_bow_cross_score(const uint32_t* __restri
     scores[(size_t)t * n_sets + r] = -s / 2.0;
 }
 
+// ---- cross-stream exchange format ---------------------------------------------------------
+// One "set" = the BoW vectors of one stream's batch as they travel in the all-gather: for every frame k_max x
+// {u32 word, f32 value} (ascending words, zero padded), then the per-frame word counts:
+//   uint2 vec[n_frames][k_max];  int32 count[n_frames];            set stride = n_frames * (2 k_max + 1) dwords
+// k_bow_pack writes the local batch in that form; k_bow_cross_packed scores frame t of set `self` against frame t
+// of every set (L1Scoring::score on the f32-rounded values, summed in ascending word order like the reference's
+// map iteration), entirely from the gathered buffer, so it may run on any stream after the collective.
+__global__ __launch_bounds__(256) void k_bow_pack(const uint32_t* __restrict__ bwords, const double* __restrict__ bvalues,
+                                                  const int32_t* __restrict__ bn, int cap, int n_frames, int k_max,
+                                                  uint32_t* __restrict__ out, uint32_t* __restrict__ flags)
+{
+    const int t = blockIdx.x;
+    const int n = bn[t];
+    uint2* dst = reinterpret_cast<uint2*>(out) + (size_t)t * k_max;
+    for(int i = threadIdx.x; i < k_max; i += 256)
+    {
+        uint2 e = make_uint2(0u, 0u);
+        if(i < n)
+            e = make_uint2(bwords[(size_t)t * cap + i], __float_as_uint((float)bvalues[(size_t)t * cap + i]));
+        dst[i] = e;
+    }
+    if(threadIdx.x == 0)
+    {
+        out[(size_t)n_frames * k_max * 2 + t] = (uint32_t)min(n, k_max);
+        if(n > k_max)
+            atomicOr(flags, kFlagBowPackOverflow);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bow_cross_packed(const uint32_t* __restrict__ sets, int n_sets, int self,
+                                                          int n_frames, int k_max, double* __restrict__ scores)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm_cross[]; // [k_max] words, [k_max] f32 values
+    uint32_t* lw = sm_cross;
+    float* lv = reinterpret_cast<float*>(sm_cross + k_max);
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t stride = (size_t)n_frames * (2 * (size_t)k_max + 1);
+    const uint32_t* mine = sets + stride * self;
+    const int n1 = min((int)mine[(size_t)n_frames * k_max * 2 + t], k_max);
+    for(int i = tid; i < n1; i += 256)
+    {
+        const uint2 e = reinterpret_cast<const uint2*>(mine)[(size_t)t * k_max + i];
+        lw[i] = e.x;
+        lv[i] = __uint_as_float(e.y);
+    }
+    __syncthreads();
+    for(int r = wave; r < n_sets; r += 4)
+    {
+        const uint32_t* other = sets + stride * r;
+        const int n2 = min((int)other[(size_t)n_frames * k_max * 2 + t], k_max);
+        const uint2* ov = reinterpret_cast<const uint2*>(other) + (size_t)t * k_max;
+        double s = 0.0;
+        for(int base = 0; base < n2; base += 64)
+        {
+            const int i = base + lane;
+            double c = 0.0;
+            bool found = false;
+            if(i < n2)
+            {
+                const uint2 e = ov[i];
+                int lo = 0, hi = n1; // first local word >= e.x
+                while(lo < hi)
+                {
+                    const int mid = (lo + hi) >> 1;
+                    if(lw[mid] < e.x)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if(lo < n1 && lw[lo] == e.x)
+                {
+                    const double vi = (double)lv[lo], wi = (double)__uint_as_float(e.y);
+                    c = fabs(vi - wi) - fabs(vi) - fabs(wi);
+                    found = true;
+                }
+            }
+            unsigned long long m = __ballot(found);
+            while(m) // ascending word order = ascending lane order within the chunk
+            {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(c), l);
+                const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(__double_as_longlong(c) >> 32), l);
+                s += __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo32));
+            }
+        }
+        if(lane == 0)
+            scores[(size_t)t * n_sets + r] = -s / 2.0;
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 #define BHIPCHK(c, call)                                                                                               \
     do                                                                                                                 \
@@ -1012,6 +1104,41 @@ int mslam_hip_bow_cross_score_dev(mslam_hip_ctx* c, const uint32_t* d_words, con
     const int total = c->n_last * n_sets;
     hipLaunchKernelGGL(k_bow_cross_score, dim3((total + 63) / 64), dim3(64), 0, c->stream, b->d_bwords, b->d_bvalues,
                        b->d_bn, b->cap, c->n_last, d_words, d_values, d_n, n_sets, capacity, b->B, d_scores);
+    BHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_pack_dev(mslam_hip_ctx* c, int k_max, uint32_t* d_out)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    const BowState* b = c->bow;
+    if(!d_out || k_max < 1)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_pack_dev: bad argument");
+    if(c->n_last < 1)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_pack_dev: no BoW batch");
+    hipLaunchKernelGGL(k_bow_pack, dim3(c->n_last), dim3(256), 0, c->stream, b->d_bwords, b->d_bvalues, b->d_bn, b->cap,
+                       c->n_last, k_max, d_out, c->d_flags);
+    BHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_cross_score_packed_dev(mslam_hip_ctx* c, const uint32_t* d_sets, int n_sets, int self_set, int n_frames,
+                                         int k_max, double* d_scores, void* stream)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    BHIPCHK(c, hipSetDevice(c->p.device));
+    if(!d_sets || !d_scores || n_sets < 1 || self_set < 0 || self_set >= n_sets || n_frames < 1 || k_max < 1 ||
+       k_max > 16384)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_cross_score_packed_dev: bad argument");
+    const size_t lds = (size_t)k_max * 8;
+    if(lds > 48 * 1024)
+        BHIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_cross_packed),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_bow_cross_packed, dim3(n_frames), dim3(256), lds, stream ? (hipStream_t)stream : c->stream, d_sets,
+                       n_sets, self_set, n_frames, k_max, d_scores);
     BHIPCHK(c, hipGetLastError());
     return MSLAM_HIP_OK;
 }

@@ -3,10 +3,15 @@
 One process per GPU, one camera stream per process (torch.distributed: backend "nccl" = RCCL over
 xGMI on the GPU box, "gloo" in CPU tests).  ORB extraction, matching and the per-stream BoW database
 need no communication at all — frames of different streams are independent.  The only exchange step
-is this one: after a batch, every rank all-gathers its per-frame BoW vectors (padded sparse vectors:
-k_max x {u32 word, f64 value} + a count), then scores its own frame t against frame t of every other
-stream.  The payload is small (k_max = 2048 -> 24.6 KB per frame), so the all-gather is latency-bound
-and a single fused collective per batch is the right shape for the point-to-point xGMI mesh.
+is this one: after a batch, every rank contributes its per-frame BoW vectors in the wire format of
+include/mslam_hip.h (`mslam_hip_bow_pack_dev`): per frame k_max x {u32 word, f32 value} + a count,
+k_max = 2048 -> 16 KB per frame, and ONE `all_gather_into_tensor` per batch moves all of them (a batch
+is one collective: fewer, larger messages suit the point-to-point xGMI mesh).  Every rank then scores
+its frame t against frame t of every other stream from the gathered buffer alone.
+
+GPU path (`step_gpu`): pack -> all-gather -> score are enqueued on a communication stream behind an
+event of the context's stream — no host synchronisation — so the collective of batch i overlaps the
+extraction of batch i+1; `finish()` joins the two streams.
 Nothing like this exists in the reference (single process, single camera).
 """
 import numpy as np
@@ -23,8 +28,37 @@ class DeviceArray:
 
 
 def view_as_tensor(ptr, shape, dtype):
-    typestr = {torch.int32: "<i4", torch.float64: "<f8", torch.uint8: "|u1", torch.float32: "<f4"}[dtype]
+    typestr = {torch.int32: "<i4", torch.float64: "<f8", torch.uint8: "|u1", torch.float32: "<f4",
+               torch.int16: "<i2"}[dtype]
     return torch.as_tensor(DeviceArray(ptr, shape, typestr), device="cuda")
+
+
+def set_dwords(n_frames, k_max):
+    """dwords of one stream's batch in the exchange format"""
+    return n_frames * (2 * k_max + 1)
+
+
+def pack_vectors(words, values, counts, k_max):
+    """torch restatement of mslam_hip_bow_pack_dev for host-side callers and CPU tests: words [B,cap] int32 (bit
+    pattern of the u32 ids), values [B,cap] float64, counts [B] int32 -> int32 [B*(2*k_max+1)]."""
+    B = words.shape[0]
+    if int(counts.max()) > k_max:
+        raise ValueError("a BoW vector has more than k_max=%d words" % k_max)
+    cap = min(words.shape[1], k_max)
+    live = torch.arange(cap, device=words.device)[None, :] < counts[:, None]
+    vec = torch.zeros((B, k_max, 2), dtype=torch.int32, device=words.device)
+    vec[:, :cap, 0] = torch.where(live, words[:, :cap], torch.zeros_like(words[:, :cap]))
+    f32 = values[:, :cap].to(torch.float32).view(torch.int32)
+    vec[:, :cap, 1] = torch.where(live, f32, torch.zeros_like(f32))
+    return torch.cat([vec.reshape(-1), counts.to(torch.int32)])
+
+
+def unpack_set(buf, n_frames, k_max):
+    """one gathered set -> (words [B,k_max] uint32, values [B,k_max] float32 widened to float64, counts [B]) as numpy"""
+    a = buf.cpu().numpy()
+    vec = a[:n_frames * k_max * 2].reshape(n_frames, k_max, 2)
+    return (vec[:, :, 0].view(np.uint32).copy(), vec[:, :, 1].copy().view(np.float32).astype(np.float64),
+            a[n_frames * k_max * 2:].copy())
 
 
 class CrossStreamLoopCandidates:
@@ -33,59 +67,81 @@ class CrossStreamLoopCandidates:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._comm = None      # communication stream (GPU path)
+        self._bufs = {}        # (n_frames, slot) -> (local set, gathered sets, scores)
+        self._slot = 0
+        self._pack_done = None
+        self.collectives = 0   # all-gathers issued (one per batch)
 
     # ---- the exchange step -------------------------------------------------------------------
-    def all_gather_vectors(self, words, values, counts):
-        """words [B,k] int32 (bit pattern of the u32 ids), values [B,k] float64, counts [B] int32 ->
-        (W [world,B,k], V [world,B,k], N [world,B]).  One collective per tensor, same device as the inputs."""
-        if int(counts.max()) > self.k_max:
-            raise ValueError("a BoW vector has more than k_max=%d words" % self.k_max)
-        w = words[:, :self.k_max].contiguous()
-        v = values[:, :self.k_max].contiguous()
-        n = counts.contiguous()
-        W = torch.empty((self.world,) + tuple(w.shape), dtype=w.dtype, device=w.device)
-        V = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=v.device)
-        N = torch.empty((self.world,) + tuple(n.shape), dtype=n.dtype, device=n.device)
-        if self.world > 1:
-            # outputs are the contiguous slices W[r] etc.; works for both nccl (RCCL) and gloo
-            dist.all_gather(list(W.unbind(0)), w, group=self.group)
-            dist.all_gather(list(V.unbind(0)), v, group=self.group)
-            dist.all_gather(list(N.unbind(0)), n, group=self.group)
+    def all_gather_sets(self, local_set, out=None):
+        """ONE collective per batch: local_set int32 [set_dwords] -> int32 [world, set_dwords]"""
+        if out is None:
+            out = torch.empty((self.world, local_set.numel()), dtype=local_set.dtype, device=local_set.device)
+        if self.world > 1 and local_set.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks on one GPU): gloo moves host memory, so bounce through it
+            torch.cuda.current_stream().synchronize()
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h_out.view(-1), local_set.cpu(), group=self.group)
+            out.copy_(h_out)
+        elif self.world > 1:
+            dist.all_gather_into_tensor(out.view(-1), local_set, group=self.group)
         else:
-            W[0], V[0], N[0] = w, v, n
-        return W, V, N
+            out[0].copy_(local_set)
+        self.collectives += 1
+        return out
 
     # ---- GPU path: vectors come straight out of the context's BoW view --------------------------
-    def step_gpu(self, ctx):
-        """After ctx.bow_batch_dev(): gather all streams' vectors and score own frame t against every
-        stream's frame t.  Returns scores [B, world] (float64 cuda tensor; column `rank` is the
-        self-score)."""
-        v = ctx.bow_view()
-        B, cap = ctx.params.max_batch, v.capacity
-        words = view_as_tensor(v.words, (B, cap), torch.int32)
-        values = view_as_tensor(v.values, (B, cap), torch.float64)
-        counts = view_as_tensor(v.n_words, (B,), torch.int32)
-        torch.cuda.current_stream().synchronize()
-        ctx.sync()  # the context runs on its own stream
-        W, V, N = self.all_gather_vectors(words, values, counts)
-        scores = torch.zeros((B, self.world), dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize()
-        ctx.bow_cross_score_dev(W.data_ptr(), V.data_ptr(), N.data_ptr(), self.world, self.k_max, scores.data_ptr())
-        ctx.sync()
+    def _buffers(self, n_frames):
+        key = (n_frames, self._slot)
+        if key not in self._bufs:
+            n = set_dwords(n_frames, self.k_max)
+            self._bufs[key] = (torch.empty(n, dtype=torch.int32, device="cuda"),
+                               torch.empty((self.world, n), dtype=torch.int32, device="cuda"),
+                               torch.zeros((n_frames, self.world), dtype=torch.float64, device="cuda"))
+        return self._bufs[key]
+
+    def step_gpu(self, ctx, ctx_stream, n_frames):
+        """After ctx.bow_batch_dev() on `ctx_stream` (the torch stream the context was created on): pack the batch's
+        vectors on that stream, then — on the communication stream, behind an event — all-gather the sets of all
+        streams and score own frame t against every stream's frame t.  Nothing here waits on the host.  Returns
+        the scores tensor [n_frames, world] (float64, cuda; column `rank` is the self-score), valid once
+        `finish()` (or a wait on the communication stream) has been called; two buffer sets alternate, so a
+        result stays intact until the second-next call."""
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        local, gathered, scores = self._buffers(n_frames)
+        self._slot ^= 1
+        # these buffers were last used two steps ago by the communication stream
+        ctx_stream.wait_stream(self._comm)
+        ctx.bow_pack_dev(self.k_max, local.data_ptr())            # on the context's stream
+        self._comm.wait_stream(ctx_stream)
+        with torch.cuda.stream(self._comm):
+            self.all_gather_sets(local, gathered)
+            ctx.bow_cross_score_packed_dev(gathered.data_ptr(), self.world, self.rank, n_frames, self.k_max,
+                                           scores.data_ptr(), stream=self._comm.cuda_stream)
         return scores
 
-    # ---- generic path (CPU tests): the scorer is injected ---------------------------------------
+    def finish(self, ctx_stream=None):
+        """join the communication stream (host wait, and optionally make `ctx_stream` wait for it)"""
+        if self._comm is not None:
+            if ctx_stream is not None:
+                ctx_stream.wait_stream(self._comm)
+            self._comm.synchronize()
+
+    # ---- generic path (CPU tests): same format, same collective; the scorer is injected ----------
     def step_with(self, words, values, counts, scorer):
-        W, V, N = self.all_gather_vectors(words, values, counts)
+        """words/values/counts as in pack_vectors (CPU tensors); scorer(w1, v1, w2, v2) -> float is applied to the
+        vectors exactly as transmitted (f32 values widened to f64)."""
         B = words.shape[0]
+        sets = self.all_gather_sets(pack_vectors(words, values, counts, self.k_max))
+        un = [unpack_set(sets[r], B, self.k_max) for r in range(self.world)]
+        mw, mv, mn = un[self.rank]
         out = np.zeros((B, self.world))
         for t in range(B):
-            n1 = int(counts[t])
-            w1 = words[t, :n1].numpy().view(np.uint32)
-            v1 = values[t, :n1].numpy()
             for r in range(self.world):
-                n2 = int(N[r, t])
-                out[t, r] = scorer(w1, v1, W[r, t, :n2].numpy().view(np.uint32), V[r, t, :n2].numpy())
+                w2, v2, n2 = un[r]
+                out[t, r] = scorer(mw[t, :mn[t]], mv[t, :mn[t]], w2[t, :n2[t]], v2[t, :n2[t]])
         return out
 
     @staticmethod

@@ -1,6 +1,8 @@
-"""world_size-2 gloo test of the multi-stream exchange (the only collective on the path): every rank
-all-gathers its BoW vectors and scores its frame t against the other stream's frame t.  The scorer
-injected here is the oracle (test infrastructure); on the GPU box the same class calls the HIP kernel."""
+"""world_size-2 gloo test of the multi-stream exchange (the only collective on the path): every rank packs its BoW
+vectors into the exchange format (k_max x {u32 word, f32 value} + count per frame), ONE all_gather_into_tensor per
+batch moves them, and every rank scores its frame t against the other stream's frame t from the gathered buffer.
+The same class, format and collective run on the GPU box (step_gpu: HIP pack + HIP scorer on the gathered sets);
+the scorer injected here is the oracle (test infrastructure)."""
 import os
 import sys
 
@@ -38,6 +40,17 @@ def _worker(rank, world, port, q):
     x = CrossStreamLoopCandidates(k_max=K)
     assert (x.world, x.rank) == (world, rank)
     scores = x.step_with(words, values, counts, orc.bow_score_l1)
+    assert x.collectives == 1                     # one fused collective per batch
+    # the wire format round-trips: what rank r unpacks of its own set is its vectors with f32 values
+    from modular_slam_amd.multi_stream import pack_vectors, unpack_set, set_dwords
+    mine = pack_vectors(words, values, counts, K)
+    assert mine.numel() == set_dwords(B, K) == B * (2 * K + 1)
+    w, v, n = unpack_set(mine, B, K)
+    for t in range(B):
+        k = int(counts[t])
+        assert n[t] == k and np.array_equal(w[t, :k], words[t, :k].numpy().view(np.uint32))
+        assert np.array_equal(v[t, :k], values[t, :k].numpy().astype(np.float32).astype(np.float64))
+        assert not w[t, k:].any() and not v[t, k:].any()
     q.put((rank, scores, [(int(counts[t]), words[t, :5].tolist()) for t in range(B)]))
     dist.barrier()
     dist.destroy_process_group()
@@ -60,6 +73,7 @@ def test_all_gather_and_cross_scores_world2():
     s0, s1 = res[0][0], res[1][0]
     assert s0.shape == (2, 2) and s1.shape == (2, 2)
     # self scores are 1 (up to rounding), cross scores are symmetric between the two ranks
-    assert np.allclose(np.diag(s0[:, [0, 0]])[:1], 1.0) and abs(s0[0, 0] - 1) < 1e-9 and abs(s1[1, 1] - 1) < 1e-9
+    # (values travel as f32: a self score is 1 up to the f32 rounding of the normalised weights)
+    assert abs(s0[0, 0] - 1) < 1e-6 and abs(s0[1, 0] - 1) < 1e-6 and abs(s1[1, 1] - 1) < 1e-6
     assert np.array_equal(s0[:, 1], s1[:, 0])
     assert (s0[:, 1] > 0.05).all() and (s0[:, 1] < 1).all()        # overlapping views of one scene

@@ -102,25 +102,62 @@ def test_bow_batch_device(pkg, orc, synth_frames):
 
 
 def test_cross_stream_scores(pkg, orc, synth_frames):
-    """the multi-GPU exchange step on one rank: all-gather (trivial at world 1) + HIP cross scoring"""
+    """the multi-GPU exchange step on one rank: HIP pack -> all-gather (trivial at world 1) -> HIP scoring of the
+    gathered sets on the communication stream, against the oracle on the vectors as transmitted (f32 values);
+    then the scorer alone on three hand-built sets; and the f64 form on explicit foreign vectors"""
     import torch
-    from modular_slam_amd.multi_stream import CrossStreamLoopCandidates
+    from modular_slam_amd.multi_stream import CrossStreamLoopCandidates, pack_vectors, set_dwords
     blob = synth.make_vocabulary(10, 3)
     V = orc.Vocabulary(blob)
     frames = synth_frames[:6]
     dev = torch.from_numpy(frames).cuda()
     B, K, k_max = 3, 4096, 2048
-    c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K)
+    ts = torch.cuda.Stream()
+    c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K, stream=ts.cuda_stream)
     c.bow_load(blob)
     vecs = [V.bow_vector(orc.detect(f, orc.params())["desc"]) for f in frames]
+    as_sent = [(w, v.astype(np.float32).astype(np.float64)) for w, v in vecs]
+    x = CrossStreamLoopCandidates(k_max=k_max)
+    for rep in range(3):                                   # the two buffer sets alternate
+        c.detect_batch_dev(dev[3 * (rep & 1):].data_ptr(), B)
+        c.bow_batch_dev(False)
+        s = x.step_gpu(c, ts, B)
+        x.finish(ts)
+        c.sync()
+        s = s.cpu().numpy()
+        assert s.shape == (B, 1)
+        for t in range(B):
+            v = as_sent[3 * (rep & 1) + t]
+            assert s[t, 0] == orc.bow_score_l1(*v, *v)
+    assert x.collectives == 3
+    # three gathered sets built on the host in the wire format: own = frames 0..2, foreign = 3..5 and 1,2,0
+    sets_idx = [[0, 1, 2], [3, 4, 5], [1, 2, 0]]
+    packed = []
+    for ids in sets_idx:
+        W = torch.zeros((B, k_max), dtype=torch.int32)
+        Vv = torch.zeros((B, k_max), dtype=torch.float64)
+        N = torch.zeros(B, dtype=torch.int32)
+        for t, i in enumerate(ids):
+            n = len(vecs[i][0])
+            W[t, :n] = torch.from_numpy(vecs[i][0].view(np.int32))
+            Vv[t, :n] = torch.from_numpy(vecs[i][1])
+            N[t] = n
+        packed.append(pack_vectors(W, Vv, N, k_max))
+    G = torch.stack(packed).cuda()
+    assert G.shape == (3, set_dwords(B, k_max))
+    for me in range(3):
+        out = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        c.bow_cross_score_packed_dev(G.data_ptr(), 3, me, B, k_max, out.data_ptr())
+        c.sync()
+        out = out.cpu().numpy()
+        for r, ids in enumerate(sets_idx):
+            for t, i in enumerate(ids):
+                assert out[t, r] == orc.bow_score_l1(*as_sent[sets_idx[me][t]], *as_sent[i])
+    assert CrossStreamLoopCandidates.candidates(out, rank=-1, min_score=0.0)
+    # the f64 form: local vectors of the last BoW batch against explicit foreign vectors
     c.detect_batch_dev(dev.data_ptr(), B)
     c.bow_batch_dev(False)
-    x = CrossStreamLoopCandidates(k_max=k_max)
-    s = x.step_gpu(c).cpu().numpy()
-    assert s.shape == (B, 1)
-    for t in range(B):
-        assert s[t, 0] == orc.bow_score_l1(*vecs[t], *vecs[t])
-    # two foreign streams: frames 3..5 and frames 1,2,0
     sets = [[3, 4, 5], [1, 2, 0]]
     W = torch.zeros((2, B, k_max), dtype=torch.int32)
     Vv = torch.zeros((2, B, k_max), dtype=torch.float64)
@@ -140,7 +177,6 @@ def test_cross_stream_scores(pkg, orc, synth_frames):
     for r, ids in enumerate(sets):
         for t, i in enumerate(ids):
             assert out[t, r] == orc.bow_score_l1(*vecs[t], *vecs[i])
-    assert CrossStreamLoopCandidates.candidates(out, rank=-1, min_score=0.0)
     c.close()
 
 
