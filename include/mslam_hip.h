@@ -38,7 +38,8 @@ typedef struct mslam_hip_ctx mslam_hip_ctx;
  * (distributed_cv_feature.cpp:1184-1186): orb_params("orb", 1.2f, 8, 20, 7), min node area 1000. */
 typedef struct
 {
-    int32_t width, height;  /* frame size every call on this context uses (reference: 640x480)            */
+    int32_t width, height;  /* frame size every call on this context uses (reference: 640x480); 0 x 0 = a
+                             * context without detector (matcher / BoW only: no pyramid buffers are allocated)    */
     int32_t max_batch;      /* frames per batched device launch, >= 1                                      */
     int32_t n_levels;       /* pyramid levels (8)                                                          */
     float scale_factor;     /* pyramid scale (1.2f); level scales are the float32 chain of :411-420        */
@@ -166,6 +167,8 @@ int mslam_hip_bow_score(mslam_hip_ctx* ctx, const uint32_t* w1, const double* v1
 int mslam_hip_bow_db_add(mslam_hip_ctx* ctx, const uint8_t* desc, int n, int* entry_id);
 int mslam_hip_bow_db_query(mslam_hip_ctx* ctx, const uint8_t* desc, int n, int max_results, int32_t* entry_ids,
                            double* scores, int* n_results);
+/* IRelocalizer::removeKeyframe: the entry is never reported again (its id is not reused). */
+int mslam_hip_bow_db_remove(mslam_hip_ctx* ctx, int entry_id);
 int mslam_hip_bow_db_clear(mslam_hip_ctx* ctx);
 /* Batched device form: transform every frame of the last detect batch into a BoW vector, score it
  * against the database (all entries), then add it as a new entry.  Per frame: best entry and score. */

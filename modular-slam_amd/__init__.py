@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host", "mslam_hip_backproject", "mslam_hip_backproject_batch_dev",
     "mslam_hip_get_points_view", "mslam_hip_set_matcher", "mslam_hip_get_matcher",
     "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
-    "mslam_hip_join_matcher",
+    "mslam_hip_join_matcher", "mslam_hip_bow_db_remove",
 ]
 
 
@@ -275,6 +275,9 @@ class Context:
         self._chk(self.L.mslam_hip_bow_db_query(self._h, _p(d), len(d), max_results, _p(ids), _p(sc), C.byref(n)))
         return ids[:n.value].copy(), sc[:n.value].copy()
 
+    def bow_db_remove(self, entry_id):
+        self._chk(self.L.mslam_hip_bow_db_remove(self._h, int(entry_id)))
+
     def bow_db_clear(self):
         self._chk(self.L.mslam_hip_bow_db_clear(self._h))
 
@@ -404,6 +407,7 @@ class HipOrbRelocalizer:
         for e, k in list(self._entry_to_keyframe.items()):
             if k is keyframe:
                 del self._entry_to_keyframe[e]
+                self.ctx.bow_db_remove(e)
 
     def relocalize(self, keypoints):
         d = np.array([k.descriptor for k in keypoints], np.uint8).reshape(-1, 32)

@@ -351,7 +351,8 @@ static void select_set(mslam_hip_ctx* c, int k)
 static int create_impl(mslam_hip_ctx* c)
 {
     const mslam_hip_params& p = c->p;
-    if(p.width <= 0 || p.height <= 0 || p.max_batch < 1 || p.n_levels < 1 || p.n_levels > kMaxLevels ||
+    const bool has_detector = !(p.width == 0 && p.height == 0); // 0 x 0: matcher / BoW only, no pyramid buffers
+    if((has_detector && (p.width <= 0 || p.height <= 0)) || p.max_batch < 1 || p.n_levels < 1 || p.n_levels > kMaxLevels ||
        !(p.scale_factor > 1.0f) || p.ini_fast_thr < 0 || p.ini_fast_thr > 255 || p.min_fast_thr < 0 ||
        p.min_fast_thr > p.ini_fast_thr || p.max_keypoints < 1 || p.max_keypoints > 65535 || p.max_candidates < 1 ||
        p.max_candidates > (1 << 22))
@@ -366,7 +367,7 @@ static int create_impl(mslam_hip_ctx* c)
         return fail(c, MSLAM_HIP_E_INVALID, "gaussian tap self-check failed");
     set_blur_taps(taps);
 
-    int rc = build_geometry(c);
+    int rc = has_detector ? build_geometry(c) : MSLAM_HIP_OK;
     if(rc)
         return rc;
     const Geometry& g = c->geom;
@@ -396,6 +397,8 @@ static int create_impl(mslam_hip_ctx* c)
         }
     }
     // tables
+    if(has_detector)
+    {
     HIPCHK(c, dmalloc(c->d_cells, c->cells.size()));
     HIPCHK(c, hipMemcpy(c->d_cells, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
     {
@@ -467,6 +470,7 @@ static int create_impl(mslam_hip_ctx* c)
         HIPCHK(c, hipMemcpy(c->d_rs_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_rs_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
     }
+    } // has_detector
     HIPCHK(c, dmalloc(c->d_ratio_thr, 257));
     {
         uint32_t w[2 * 256];
@@ -477,8 +481,12 @@ static int create_impl(mslam_hip_ctx* c)
 
     const size_t B = (size_t)p.max_batch, L = (size_t)p.n_levels, cap = (size_t)p.max_candidates;
     const size_t K = (size_t)p.max_keypoints;
-    HIPCHK(c, dmalloc(c->d_stage, (size_t)p.width * p.height * 3));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out), 16 + K * 52, hipHostMallocDefault));
+    HIPCHK(c, dmalloc(c->d_flags, 1));
+    HIPCHK(c, hipMemset(c->d_flags, 0, 4));
+    if(has_detector)
+    {
+    HIPCHK(c, dmalloc(c->d_stage, (size_t)p.width * p.height * 3));
     // + 64: the patch loads of k_describe may run a few bytes past the last row of the last frame
     HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 256));
     HIPCHK(c, dmalloc(c->d_blur, B * g.slab + 256));
@@ -497,13 +505,12 @@ static int create_impl(mslam_hip_ctx* c)
     HIPCHK(c, dmalloc(q.child_cnt, B * L * cap * 4));
     HIPCHK(c, dmalloc(q.ninfo, B * L * cap));
     HIPCHK(c, dmalloc(q.best, B * L * cap));
-    HIPCHK(c, dmalloc(c->d_flags, 1));
-    HIPCHK(c, hipMemset(c->d_flags, 0, 4));
     q.cell_cnt = c->d_cell_cnt;
     q.cell_kp = c->d_cell_kp;
     q.flags = c->d_flags;
     q.cand_cap = p.max_candidates;
     q.min_size = p.min_node_area;
+    } // has_detector
 
     for(auto& o : c->out)
     {
@@ -717,6 +724,8 @@ static int detect_prologue(mslam_hip_ctx* c)
 int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
 {
     ENTER(c);
+    if(c->p.width == 0)
+        return fail(c, MSLAM_HIP_E_INVALID, "detect_batch_dev: this context was created without a detector (0 x 0)");
     if(!d_bgr || n_frames < 1 || n_frames > c->p.max_batch)
         return fail(c, MSLAM_HIP_E_INVALID, "detect_batch_dev: n_frames outside [1, max_batch]");
     int rc = detect_prologue(c);
@@ -757,6 +766,8 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
         *n_out = 0;
     if(!bgr || !n_out || max_out < 0 || (max_out > 0 && (!xy || !desc)))
         return fail(c, MSLAM_HIP_E_INVALID, "detect: null argument");
+    if(c->p.width == 0)
+        return fail(c, MSLAM_HIP_E_INVALID, "detect: this context was created without a detector (0 x 0)");
     if(width != c->p.width || height != c->p.height)
         return fail(c, MSLAM_HIP_E_INVALID, "detect: frame size differs from the context's");
     const size_t K = (size_t)c->p.max_keypoints;
@@ -860,6 +871,8 @@ static int upload_ratio_table(mslam_hip_ctx* c, double ratio)
                 break;
         thr[d1] = n;
     }
+    // a ratio test of an earlier batch may still be reading the table on the matcher stream
+    HIPCHK(c, hipStreamSynchronize(c->stream_m));
     HIPCHK(c, hipMemcpyAsync(c->d_ratio_thr, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // thr is a stack buffer
     c->ratio_cached = ratio;
@@ -1104,7 +1117,7 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
                          size_t* n_items)
 {
     ENTER(c);
-    if(frame < 0 || frame >= c->p.max_batch || level < 0 || level >= c->geom.n_levels || !dst || !n_items)
+    if(c->p.width == 0 || frame < 0 || frame >= c->p.max_batch || level < 0 || level >= c->geom.n_levels || !dst || !n_items)
         return fail(c, MSLAM_HIP_E_INVALID, "debug_read: bad argument");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const LevelGeom& lv = c->geom.lv[level];
@@ -1146,7 +1159,7 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
 int mslam_hip_debug_counts(mslam_hip_ctx* c, int what, int32_t* out)
 {
     ENTER(c);
-    if(!out || (what != MSLAM_HIP_DBG_CANDIDATES && what != MSLAM_HIP_DBG_SELECTED))
+    if(c->p.width == 0 || !out || (what != MSLAM_HIP_DBG_CANDIDATES && what != MSLAM_HIP_DBG_SELECTED))
         return fail(c, MSLAM_HIP_E_INVALID, "debug_counts: bad argument");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // the scratch arrays are indexed by the frame's position in the batch: [frame][level]

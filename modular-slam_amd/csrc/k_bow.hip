@@ -747,8 +747,23 @@ static int bow_load_impl(mslam_hip_ctx* c, const void* blob, size_t size)
         sweight[s] = weight[nid];
     }
 
-    if(c->p.max_keypoints > 16384)
-        return bfail(c, MSLAM_HIP_E_INVALID, "bow_load: max_keypoints > 16384 is not supported by the BoW vector kernel");
+    {
+        // k_bow_score keeps the query vector and its hash table in LDS: cap * 8 + (slots + cap) * 4 bytes with
+        // slots = the power of two >= 2 * cap; check it against the device limit here, not at the first query
+        int slots = 1024, lds_max = 0;
+        while(slots < 2 * c->p.max_keypoints)
+            slots <<= 1;
+        const size_t lds = (size_t)c->p.max_keypoints * 8 + ((size_t)slots + c->p.max_keypoints) * 4;
+        if(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->p.device) != hipSuccess)
+            return bfail(c, MSLAM_HIP_E_RUNTIME, "bow_load: cannot query the LDS size");
+        if(lds > (size_t)lds_max || c->p.max_keypoints > 8192)
+        {
+            c->err = "bow_load: max_keypoints = " + std::to_string(c->p.max_keypoints) + " needs " + std::to_string(lds) +
+                     " bytes of LDS for BoW scoring (device limit " + std::to_string(lds_max) +
+                     "); create the context with max_keypoints <= 8192";
+            return MSLAM_HIP_E_INVALID;
+        }
+    }
     BowState* b = new BowState();
     b->k = k, b->L = L, b->scoring = scoring, b->weighting = weighting;
     b->n_nodes = n_nodes, b->n_words = n_words, b->max_children = max_children;
@@ -1068,6 +1083,21 @@ int mslam_hip_bow_db_query(mslam_hip_ctx* c, const uint8_t* desc, int n, int max
         scores[i] = res[i].first;
     }
     *n_results = m;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_db_remove(mslam_hip_ctx* c, int entry_id)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    BowState* b = c->bow;
+    if(entry_id < 0 || entry_id >= b->next_id)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_db_remove: no such entry");
+    if(entry_id < b->next_id - b->R)
+        return MSLAM_HIP_OK; // already out of the window
+    // an entry without words shares no word with any query: Database::query never reports it
+    BHIPCHK(c, hipMemsetAsync(b->d_rn + (entry_id % b->RP), 0, 4, c->stream));
     return MSLAM_HIP_OK;
 }
 

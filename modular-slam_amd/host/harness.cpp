@@ -6,12 +6,17 @@
 // usage: mslam_harness <plugin.so> <width> <height> <frame0.bgr> <frame1.bgr>     raw B,G,R frames
 //        mslam_harness <plugin.so> --tum <associations.txt>                       a TUM RGB-D sequence, read the way
 //                                                                                 the reference's RgbdFileProvider does
+//        mslam_harness <plugin.so> --bow <vocabulary.dbow3> <width> <height> <frame.bgr>...
+//                                    the BoW boundary: relocalizer + loop detector factories (one shared database),
+//                                    fed in the frontend's order: detect -> addKeyframe (rgbd_feature_frontend.cpp:176)
+//                                    -> detectLoop (:202); then relocalize / removeKeyframe / relocalize
 // prints one line per frame/match with an FNV-1a checksum the parity test compares with the oracle's.
 #include "mslam_interfaces.hpp"
 #include "plugin_loader.hpp"
 #include "tum_io.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
@@ -39,6 +44,51 @@ int main(int argc, char** argv)
         std::unique_ptr<mslam::IOrbFeatureDetector> detector = makeDetector();
         std::unique_ptr<mslam::IOrbMatcher> matcher = makeMatcher();
         std::printf("loaded %s\n", detector && matcher ? "ok" : "null");
+        if(argc >= 7 && std::strcmp(argv[2], "--bow") == 0)
+        {
+            setenv("MSLAM_ORB_VOCABULARY", argv[3], 1); // the reference hard-codes "orbvoc.dbow3" in the working directory
+            auto makeReloc = mslam::loadFactoryMethod<mslam::IOrbRelocalizer>(argv[1], "hipOrbRelocalizerFactory");
+            auto makeLoop = mslam::loadFactoryMethod<mslam::IOrbLoopDetector>(argv[1], "loopDetection");
+            std::unique_ptr<mslam::IOrbRelocalizer> relocalizer = makeReloc();
+            std::unique_ptr<mslam::IOrbLoopDetector> loopDetector = makeLoop();
+            const int w = std::atoi(argv[4]), h = std::atoi(argv[5]);
+            using Kf = mslam::Keyframe<mslam::slam3d::SensorState>;
+            std::vector<std::shared_ptr<Kf>> keyframes;
+            std::vector<std::vector<mslam::OrbKeypoint>> all;
+            for(int f = 0; f + 6 < argc; ++f)
+            {
+                mslam::RgbFrame frame;
+                frame.size = {w, h};
+                frame.data.resize(static_cast<std::size_t>(w) * h * 3);
+                std::ifstream in(argv[6 + f], std::ios::binary);
+                if(!in.read(reinterpret_cast<char*>(frame.data.data()), static_cast<std::streamsize>(frame.data.size())))
+                {
+                    std::fprintf(stderr, "cannot read %s\n", argv[6 + f]);
+                    return 5;
+                }
+                auto kps = detector->detect(frame);
+                auto kf = std::make_shared<Kf>();
+                kf->id = 100 + static_cast<mslam::Id>(f);
+                relocalizer->addKeyframe(kf, kps);
+                const auto loop = loopDetector->detectLoop();
+                std::printf("keyframe %d keypoints %zu loop %lld\n", f, kps.size(), loop ? (long long)loop->id : -1LL);
+                keyframes.push_back(kf);
+                all.push_back(std::move(kps));
+            }
+            for(std::size_t f = 0; f < all.size(); ++f)
+            {
+                std::printf("relocalize %zu:", f);
+                for(const auto& k : relocalizer->relocalize(all[f]))
+                    std::printf(" %llu", (unsigned long long)k->id);
+                std::printf("\n");
+            }
+            relocalizer->removeKeyframe(keyframes[0]);
+            std::printf("after remove 0:");
+            for(const auto& k : relocalizer->relocalize(all[0]))
+                std::printf(" %llu", (unsigned long long)k->id);
+            std::printf("\n");
+            return 0;
+        }
         const bool tum = argc == 4 && std::strcmp(argv[2], "--tum") == 0;
         if(argc < 6 && !tum)
             return detector && matcher ? 0 : 4;

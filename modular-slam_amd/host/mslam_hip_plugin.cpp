@@ -4,8 +4,10 @@
 //   HipOrbDetector    : IFeatureDetector<RgbFrame,u8,32>   drop-in for DistributedOrbOpenCvDetector
 //                                                           (distributed_cv_feature.cpp:1181-1222)
 //   HipOrbMatcher     : IFeatureMatcher<u8,32>             drop-in for OrbOpenCvMatcher (orb_feature.cpp:84-130)
-//   HipOrbRelocalizer : IRelocalizer + ILoopDetector       what OrbRelocalizer is wired for
+//   HipOrbRelocalizer : IRelocalizer                       what OrbRelocalizer is wired for
 //                                                           (orb_relocalizer.cpp:26-50, rgbd_feature_frontend.cpp:153,176)
+//   HipLoopDetector   : ILoopDetector                      (loop_detection.hpp:10-15, rgbd_feature_frontend.cpp:202);
+//                                                           both sit on ONE shared BoW database
 //
 // Errors: the reference interfaces have no status channel, so a non-zero C-ABI status becomes a
 // std::runtime_error carrying mslam_hip_last_error() (the reference itself lets OpenCV/DBoW3 throw,
@@ -15,10 +17,13 @@
 
 #include "../../include/mslam_hip.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -36,10 +41,11 @@ namespace
 struct Ctx
 {
     mslam_hip_ctx* h = nullptr;
-    int width = 0, height = 0;
-    void ensure(int w, int h_)
+    int width = -1, height = -1, capacity = 0;
+    // width = height = 0: a context without detector buffers (the matcher and the BoW database need none)
+    void ensure(int w, int h_, int max_keypoints = 0)
     {
-        if(h && w == width && h_ == height)
+        if(h && w == width && h_ == height && (max_keypoints == 0 || max_keypoints == capacity))
             return;
         if(h)
             mslam_hip_destroy(h);
@@ -48,11 +54,17 @@ struct Ctx
         mslam_hip_default_params(&p); // the reference's hard-coded operating point
         p.width = w;
         p.height = h_;
+        if(max_keypoints > 0)
+        {
+            p.max_keypoints = max_keypoints;
+            p.max_candidates = std::max(p.max_candidates, 4 * max_keypoints);
+        }
         const int rc = mslam_hip_create(&p, &h);
         if(rc != MSLAM_HIP_OK)
             raise(nullptr, "mslam_hip_create", rc);
         width = w;
         height = h_;
+        capacity = p.max_keypoints;
     }
     ~Ctx()
     {
@@ -77,15 +89,29 @@ class HipOrbDetector : public IOrbFeatureDetector
         std::vector<OrbKeypoint> result;
         if(sensorData.data.empty()) // distributed_cv_feature.cpp:724-727: empty image => empty result
             return result;
-        ctx.ensure(sensorData.size.width, sensorData.size.height);
-        const int cap = 8192;
-        xy.resize(2 * cap);
-        desc.resize(32 * cap);
+        const int w = sensorData.size.width, h = sensorData.size.height;
+        // The reference's output is unbounded (a std::vector).  Start from a capacity sized for the frame
+        // area (8192 at 640x480) and, if a frame yields more, rebuild the context with twice the room and
+        // run the frame again: the capacity only ever grows.
+        if(ctx.width != w || ctx.height != h)
+        {
+            const long long area = (long long)w * h;
+            wanted = (int)std::min<long long>(65535, std::max<long long>(wanted, 8192 * ((area + 307199) / 307200)));
+        }
         int n = 0;
-        const int rc = mslam_hip_detect(ctx.h, sensorData.data.data(), sensorData.size.width, sensorData.size.height, cap,
-                                        xy.data(), desc.data(), nullptr, nullptr, nullptr, &n);
-        if(rc != MSLAM_HIP_OK)
-            raise(ctx.h, "mslam_hip_detect", rc);
+        for(;;)
+        {
+            ctx.ensure(w, h, wanted);
+            xy.resize(2 * (std::size_t)ctx.capacity);
+            desc.resize(32 * (std::size_t)ctx.capacity);
+            const int rc = mslam_hip_detect(ctx.h, sensorData.data.data(), w, h, ctx.capacity, xy.data(), desc.data(),
+                                            nullptr, nullptr, nullptr, &n);
+            if(rc == MSLAM_HIP_OK)
+                break;
+            if(rc != MSLAM_HIP_E_CAPACITY || wanted >= 65535)
+                raise(ctx.h, "mslam_hip_detect", rc);
+            wanted = std::min(65535, 2 * wanted);
+        }
         result.resize(static_cast<std::size_t>(n));
         for(int i = 0; i < n; ++i)
         {
@@ -100,6 +126,7 @@ class HipOrbDetector : public IOrbFeatureDetector
 
   private:
     Ctx ctx;
+    int wanted = 0;
     std::vector<float> xy;
     std::vector<std::uint8_t> desc;
 };
@@ -110,7 +137,7 @@ class HipOrbMatcher : public IOrbMatcher
     std::vector<DescriptorMatch> match(const std::vector<OrbKeypoint>& fromDescriptors,
                                        const std::vector<OrbKeypoint>& toDescriptors) override
     {
-        ctx.ensure(640, 480); // the matcher does not depend on the frame size
+        ctx.ensure(0, 0); // the matcher needs no detector buffers
         gather_descriptors(fromDescriptors, from);
         gather_descriptors(toDescriptors, to);
         fi.resize(toDescriptors.size() + 1);
@@ -133,26 +160,47 @@ class HipOrbMatcher : public IOrbMatcher
     std::vector<std::int32_t> fi, ti;
 };
 
-class HipOrbRelocalizer : public IOrbRelocalizer, public IOrbLoopDetector
+// The BoW object both interfaces sit on.  The reference frontend holds the relocalizer and the loop detector as
+// two separate members (rgbd_feature_frontend.cpp:153 and the loopDetector it is constructed with); keyframes are
+// only ever fed through IRelocalizer::addKeyframe (:176), and ILoopDetector::detectLoop() takes no arguments
+// (loop_detection.hpp:13).  So the two adapters returned by the two factories share ONE database: what
+// addKeyframe feeds is what detectLoop() reports on.
+class BowDatabase
 {
   public:
     using KeyframePtr = std::shared_ptr<Keyframe<slam3d::SensorState>>;
 
-    // like OrbRelocalizer (orb_relocalizer.cpp:26-30): loads "orbvoc.dbow3" from the working directory and
-    // throws when it is missing.  The file must be an uncompressed DBoW3 binary vocabulary.
-    explicit HipOrbRelocalizer(const std::string& vocabularyPath = "orbvoc.dbow3")
+    // like OrbRelocalizer (orb_relocalizer.cpp:26-30): loads "orbvoc.dbow3" from the working directory and throws
+    // when it is missing.  MSLAM_ORB_VOCABULARY overrides the path (the reference hard-codes it).
+    BowDatabase()
     {
-        std::ifstream f(vocabularyPath, std::ios::binary);
+        const char* env = std::getenv("MSLAM_ORB_VOCABULARY");
+        const std::string path = env ? env : "orbvoc.dbow3";
+        std::ifstream f(path, std::ios::binary);
         if(!f)
-            throw std::runtime_error("HipOrbRelocalizer: could not open vocabulary " + vocabularyPath);
+            throw std::runtime_error("HipOrbRelocalizer: could not open vocabulary " + path);
         std::vector<char> blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-        ctx.ensure(640, 480);
+        ctx.ensure(0, 0);
         const int rc = mslam_hip_bow_load(ctx.h, blob.data(), blob.size());
         if(rc != MSLAM_HIP_OK)
             raise(ctx.h, "mslam_hip_bow_load", rc);
     }
 
-    std::vector<KeyframePtr> relocalize(const std::vector<OrbKeypoint>& keypoints) override
+    static std::shared_ptr<BowDatabase> shared()
+    {
+        static std::mutex m;
+        static std::weak_ptr<BowDatabase> live;
+        std::lock_guard<std::mutex> lock(m);
+        auto p = live.lock();
+        if(!p)
+        {
+            p = std::make_shared<BowDatabase>();
+            live = p;
+        }
+        return p;
+    }
+
+    std::vector<KeyframePtr> relocalize(const std::vector<OrbKeypoint>& keypoints, std::vector<double>* scoresOut = nullptr)
     {
         gather_descriptors(keypoints, desc);
         std::int32_t ids[64];
@@ -166,17 +214,20 @@ class HipOrbRelocalizer : public IOrbRelocalizer, public IOrbLoopDetector
         {
             auto it = entryToKeyframe.find(ids[i]);
             if(it != entryToKeyframe.end())
+            {
                 out.push_back(it->second);
+                if(scoresOut)
+                    scoresOut->push_back(scores[i]);
+            }
         }
         return out;
     }
 
-    void addKeyframe(KeyframePtr keyframe, const std::vector<OrbKeypoint>& keypoints) override
+    void addKeyframe(KeyframePtr keyframe, const std::vector<OrbKeypoint>& keypoints)
     {
         if(keypoints.empty()) // the reference asserts non-empty (orb_relocalizer.cpp:42)
             return;
-        // loop candidate = best earlier keyframe for the one being added (ILoopDetector has no arguments,
-        // loop_detection.hpp:13, so it is fed here — rgbd_feature_frontend.cpp:176 is the only feed point)
+        // loop candidate = best earlier keyframe for the one being added
         const auto candidates = relocalize(keypoints);
         lastLoop = candidates.empty() ? nullptr : candidates.front();
         int entry = -1;
@@ -186,13 +237,25 @@ class HipOrbRelocalizer : public IOrbRelocalizer, public IOrbLoopDetector
         entryToKeyframe[entry] = std::move(keyframe);
     }
 
-    void removeKeyframe(KeyframePtr keyframe) override
+    void removeKeyframe(const KeyframePtr& keyframe)
     {
         for(auto it = entryToKeyframe.begin(); it != entryToKeyframe.end();)
-            it = it->second == keyframe ? entryToKeyframe.erase(it) : std::next(it);
+        {
+            if(it->second == keyframe)
+            {
+                const int rc = mslam_hip_bow_db_remove(ctx.h, it->first); // never scored again
+                if(rc != MSLAM_HIP_OK)
+                    raise(ctx.h, "mslam_hip_bow_db_remove", rc);
+                it = entryToKeyframe.erase(it);
+            }
+            else
+                ++it;
+        }
+        if(lastLoop == keyframe)
+            lastLoop = nullptr;
     }
 
-    KeyframePtr detectLoop() override { return lastLoop; }
+    KeyframePtr detectLoop() const { return lastLoop; }
 
   private:
     Ctx ctx;
@@ -201,11 +264,39 @@ class HipOrbRelocalizer : public IOrbRelocalizer, public IOrbLoopDetector
     KeyframePtr lastLoop;
 };
 
+class HipOrbRelocalizer : public IOrbRelocalizer
+{
+  public:
+    HipOrbRelocalizer() : db(BowDatabase::shared()) {}
+    std::vector<BowDatabase::KeyframePtr> relocalize(const std::vector<OrbKeypoint>& keypoints) override
+    {
+        return db->relocalize(keypoints);
+    }
+    void addKeyframe(BowDatabase::KeyframePtr keyframe, const std::vector<OrbKeypoint>& keypoints) override
+    {
+        db->addKeyframe(std::move(keyframe), keypoints);
+    }
+    void removeKeyframe(BowDatabase::KeyframePtr keyframe) override { db->removeKeyframe(keyframe); }
+
+  private:
+    std::shared_ptr<BowDatabase> db;
+};
+
+class HipLoopDetector : public IOrbLoopDetector
+{
+  public:
+    HipLoopDetector() : db(BowDatabase::shared()) {}
+    BowDatabase::KeyframePtr detectLoop() override { return db->detectLoop(); }
+
+  private:
+    std::shared_ptr<BowDatabase> db;
+};
+
 // ---- factories + aliases (what loadFactoryMethod<T>(lib, name) imports) -------------------------------
 std::unique_ptr<IOrbFeatureDetector> createHipOrbDetector() { return std::make_unique<HipOrbDetector>(); }
 std::unique_ptr<IOrbMatcher> createHipOrbMatcher() { return std::make_unique<HipOrbMatcher>(); }
 std::unique_ptr<IOrbRelocalizer> createHipOrbRelocalizer() { return std::make_unique<HipOrbRelocalizer>(); }
-std::unique_ptr<IOrbLoopDetector> createHipLoopDetector() { return std::make_unique<HipOrbRelocalizer>(); }
+std::unique_ptr<IOrbLoopDetector> createHipLoopDetector() { return std::make_unique<HipLoopDetector>(); }
 
 } // namespace mslam
 

@@ -73,3 +73,41 @@ def test_plugin_detect_match_parity(built, orc, bundled_frames, tmp_path):
     r2 = subprocess.run([HARNESS, PLUGIN, "--tum", assoc], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr
     assert r2.stdout.strip().splitlines() == lines
+
+
+@pytest.mark.gpu
+def test_plugin_bow_boundary(built, orc, synth_frames, tmp_path):
+    """relocalizer + loop-detector factories on ONE shared database (the frontend feeds keyframes only through
+    IRelocalizer::addKeyframe, rgbd_feature_frontend.cpp:176, and asks ILoopDetector::detectLoop(), :202):
+    detectLoop() after every addKeyframe, relocalize() for every frame, removeKeyframe() — against the oracle."""
+    import synth
+    voc = tmp_path / "orbvoc.dbow3"
+    blob = synth.make_vocabulary(10, 4, seed=5)
+    voc.write_bytes(blob)
+    order = [0, 1, 2, 0, 3, 1, 4]                       # revisits: frame 3 == frame 0, frame 5 == frame 1
+    paths = []
+    for i, fi in enumerate(order):
+        p = tmp_path / ("k%d.bgr" % i)
+        p.write_bytes(synth_frames[fi].tobytes())
+        paths.append(str(p))
+    r = subprocess.run([HARNESS, PLUGIN, "--bow", str(voc), "640", "480"] + paths, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    V = orc.Vocabulary(blob)
+    dets = [orc.detect(synth_frames[fi], orc.params()) for fi in order]
+    vecs = [V.bow_vector(d["desc"]) for d in dets]
+
+    def ranked(q, live):
+        sc = sorted(((orc.bow_score_l1(*vecs[q], *vecs[e]), e) for e in live), key=lambda x: (-x[0], x[1]))
+        return [e for s, e in sc if s > 0]
+
+    for t in range(len(order)):
+        best = ranked(t, range(t))
+        exp = "keyframe %d keypoints %d loop %d" % (t, len(dets[t]["xy"]), 100 + best[0] if best else -1)
+        assert exp in lines, (exp, lines)
+    assert "keyframe 3 keypoints %d loop 100" % len(dets[3]["xy"]) in lines      # the revisit of frame 0 is found
+    n = len(order)
+    for t in range(n):
+        assert "relocalize %d: %s" % (t, " ".join(str(100 + e) for e in ranked(t, range(n))[:4])) in lines
+    assert "after remove 0: %s" % " ".join(str(100 + e) for e in ranked(0, range(1, n))[:4]) in lines
