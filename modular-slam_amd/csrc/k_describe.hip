@@ -91,6 +91,25 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 }
 
 
+// two independent sums at once: the DPP adds of one fill the wait states of the other
+__device__ __forceinline__ void wave_sum_dpp2(int a, int b, int& ra, int& rb)
+{
+    a += __builtin_amdgcn_update_dpp(0, a, 0x111, 0xF, 0xF, true);
+    b += __builtin_amdgcn_update_dpp(0, b, 0x111, 0xF, 0xF, true);
+    a += __builtin_amdgcn_update_dpp(0, a, 0x112, 0xF, 0xF, true);
+    b += __builtin_amdgcn_update_dpp(0, b, 0x112, 0xF, 0xF, true);
+    a += __builtin_amdgcn_update_dpp(0, a, 0x114, 0xF, 0xE, true);
+    b += __builtin_amdgcn_update_dpp(0, b, 0x114, 0xF, 0xE, true);
+    a += __builtin_amdgcn_update_dpp(0, a, 0x118, 0xF, 0xC, true);
+    b += __builtin_amdgcn_update_dpp(0, b, 0x118, 0xF, 0xC, true);
+    a += __builtin_amdgcn_update_dpp(0, a, 0x142, 0xA, 0xF, true);
+    b += __builtin_amdgcn_update_dpp(0, b, 0x142, 0xA, 0xF, true);
+    a += __builtin_amdgcn_update_dpp(0, a, 0x143, 0xC, 0xF, true);
+    b += __builtin_amdgcn_update_dpp(0, b, 0x143, 0xC, 0xF, true);
+    ra = __builtin_amdgcn_readlane(a, 63);
+    rb = __builtin_amdgcn_readlane(b, 63);
+}
+
 // Every WAVE is an independent worker (no workgroup barriers): it takes kBatch keypoints at a time through
 //  0. one LANE per keypoint: which level, which candidate word (kept in that lane's registers and
 //     broadcast later with v_readlane);
@@ -152,36 +171,71 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     }
     const uint8_t* pyr = a.pyr + frame * g.slab;
     const uint8_t* blur = a.blur + frame * g.slab;
+    auto bc = [&](uint32_t v, int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); };
+    // lane l (< n_levels <= 16) keeps level l's cumulative keypoint count, row pitch, slab offset and scale
+    int lv_cum = 0;
+    uint32_t lv_pitch = 16, lv_offset = 0, lv_scale = 0;
+    {
+        const int ll = min(lane, g.n_levels - 1);
+        int c = lane < g.n_levels ? (int)sel_cnt[ll] : 0;
+#pragma unroll
+        for(int o = 1; o < kMaxLevels; o <<= 1)
+        {
+            const int t = __shfl_up(c, o);
+            c += lane >= o ? t : 0;
+        }
+        lv_cum = c;
+        const LevelGeom* lvp = &g.lv[0];
+        lv_pitch = (uint32_t)lvp[ll].pitch;
+        lv_offset = (uint32_t)lvp[ll].offset;
+        lv_scale = __float_as_uint(lvp[ll].scale);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // the table is in registers: no waits for it inside the batch loop
 
     for(int base = (bx * 4 + wave) * kBatch; base < n_kp; base += kWavesPerFrame * kBatch)
     {
         const int n_here = min(kBatch, n_kp - base); // wave-uniform
 
-        // ---- 0. one lane per keypoint: which level, which candidate word
+        // ---- 0. one lane per keypoint: which level, which candidate word, and everything phases A and C need to
+        //         address its two windows (byte offsets inside the frame slab, row pitch, sub-16 shifts).  The level
+        //         loop runs on a wave-uniform counter, so the level geometry comes through scalar loads ONCE per
+        //         batch; the per-keypoint phases then only broadcast lane k's registers (v_readlane).
         uint32_t my_kp = 0;
         int my_level = 0;
-        if(lane < n_here)
+        uint32_t my_doff = 0, my_poff = 0, my_pitch = 16, my_sh = 0;
+        float my_scale = 1.f;
         {
-            int local = base + lane;
+            const int idx = base + lane; // position in the frame's concatenated keypoint list (:787-808)
+            int first = 0;               // list position of the level's first keypoint
+            uint32_t lofs = 0;
+#pragma unroll 1
             for(int l = 0; l < g.n_levels; ++l)
             {
-                const int c = (int)sel_cnt[l];
-                if(local < c)
-                {
-                    my_level = l;
-                    break;
-                }
-                local -= c;
+                // lane l holds level l's cumulative count and geometry (loaded once per wave, above): the level
+                // search is 4 broadcasts + selects per level, no memory access
+                const int cum = __builtin_amdgcn_readlane(lv_cum, l);
+                const bool here = idx >= first && idx < cum;
+                my_level = here ? l : my_level;
+                my_pitch = here ? bc(lv_pitch, l) : my_pitch;
+                lofs = here ? bc(lv_offset, l) : lofs;
+                my_scale = here ? __uint_as_float(bc(lv_scale, l)) : my_scale;
+                my_kp = here ? (uint32_t)(idx - first) : my_kp; // index inside the level, replaced by the word below
+                first = cum;
             }
-            my_kp = a.sel[(frame * g.n_levels + my_level) * (size_t)a.cand_cap + local];
+            if(lane < n_here)
+            {
+                my_kp = a.sel[(frame * g.n_levels + my_level) * (size_t)a.cand_cap + my_kp];
+                const int px = kp_x(my_kp) + kBorder, py = kp_y(my_kp) + kBorder; // :966-967
+                my_doff = lofs + (uint32_t)(py - 15) * my_pitch + (uint32_t)((px - 15) & ~15);
+                my_poff = lofs + (uint32_t)(py - kPatchR) * my_pitch + (uint32_t)((px - kPatchR) & ~15);
+                my_sh = (uint32_t)((px - 15) & 15) | ((uint32_t)((px - kPatchR) & 15) << 4);
+            }
         }
-        auto kp_of = [&](int k, int& px, int& py) -> const LevelGeom& {
-            const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)my_kp, k);
-            px = kp_x(p) + kBorder; // :966-967
-            py = kp_y(p) + kBorder;
-            return g.lv[__builtin_amdgcn_readlane(my_level, k)];
-        };
-
+        // The candidate words are in registers from here on: without this explicit wait the compiler re-inserts
+        // "s_waitcnt vmcnt(0)" in front of every later use in a conditional block — i.e. in front of each LDS-DMA
+        // issue of the prologues below, which would drain the DMA just issued and serialise them.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- A. moments
         int my_m10 = 0, my_m01 = 0;
         {
@@ -189,10 +243,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
             // aligned start (two global_load_lds_dwordx4 per keypoint into the ring phase C uses later); lane t (+64q)
             // then reads dword (row t/8, column group t%8) of the window as two aligned LDS dwords + v_alignbyte
             auto dma_disc = [&](int k, int buf) {
-                int px, py;
-                const LevelGeom& lv = kp_of(k, px, py);
-                const uint8_t* src = pyr + lv.offset + (py - 15) * lv.pitch + ((px - 15) & ~15);
-                const uint32_t pitch = (uint32_t)lv.pitch;
+                const uint8_t* src = pyr + bc(my_doff, k);
+                const uint32_t pitch = bc(my_pitch, k);
 #pragma unroll
                 for(int q = 0; q < 2; ++q)
                 {
@@ -207,8 +259,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 }
             };
             auto reduce = [&](int k, int buf) {
-                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)my_kp, k);
-                const int sh = (kp_x(p) + kBorder - 15) & 15;
+                const int sh = (int)(bc(my_sh, k) & 15u);
                 const uint32_t* d = patch[wave][buf] + (sh >> 2);
                 int m10 = 0, m01 = 0;
 #pragma unroll
@@ -225,8 +276,10 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     m10 = __builtin_amdgcn_sdot4((int)x, (int)wu[q], m10, false);
                     m01 = __builtin_amdgcn_sdot4((int)x, (int)wv[q], m01, false);
                 }
-                { const int t10 = wave_sum_dpp(m10); my_m10 = lane == k ? t10 : my_m10; }
-                { const int t01 = wave_sum_dpp(m01); my_m01 = lane == k ? t01 : my_m01; }
+                int t10, t01;
+                wave_sum_dpp2(m10, m01, t10, t01);
+                my_m10 = lane == k ? t10 : my_m10;
+                my_m01 = lane == k ? t01 : my_m01;
             };
             constexpr int kDepthA = kPatchBufs - 1;
 #pragma unroll
@@ -252,23 +305,42 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
             }
         }
 
-        // ---- B. one lane per keypoint: angle, cos/sin, scalar outputs
-        float my_ca = 0.f, my_sa = 0.f;
+        // The blurred patches of the batch's first keypoints are requested BEFORE phase B: they only need addresses,
+        // and phase B (one lane per keypoint, scalar-like float code) then runs under their latency.  (All ring
+        // slots are free here: phase A has reduced its last window.)
+        auto dma_patch = [&](int k, int buf) {
+            const uint8_t* bsrc = blur + bc(my_poff, k);
+            const uint32_t pitch = bc(my_pitch, k);
+#pragma unroll
+            for(int q = 0; q < 3; ++q)
+            {
+                const uint32_t t = (uint32_t)lane + 64u * q;
+                if(t < (uint32_t)(kPatchRows * 4))
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(bsrc + __umul24(t >> 2, pitch) + 16u * (t & 3u)),
+                        (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+            }
+        };
+        constexpr int kDepth = kPatchBufs - 1; // patches in flight beside the one being sampled
+#pragma unroll
+        for(int i = 0; i < kDepth; ++i)
+            if(i < n_here)
+                dma_patch(i, i);
+
+        // ---- B. one lane per keypoint: angle, cos/sin, scalar outputs (kept in registers and stored after phase C:
+        //         stores issued here would sit between the patch DMAs in the vmcnt queue and make phase C's counted
+        //         waits stricter than they need to be)
+        float my_ca = 0.f, my_sa = 0.f, my_angle = 0.f, my_ox = 0.f, my_oy = 0.f;
         if(lane < n_here)
         {
-            const float angle = fast_atan2_deg((float)my_m01, (float)my_m10);
-            const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0); // :574
+            my_angle = fast_atan2_deg((float)my_m01, (float)my_m10);
+            const float rad = (float)((double)my_angle * 3.14159265358979323846 / 180.0); // :574
             my_ca = util_cos(rad);
             my_sa = util_sin(rad);
-            const float scale = g.lv[my_level].scale;
             const float fx = (float)(kp_x(my_kp) + kBorder), fy = (float)(kp_y(my_kp) + kBorder);
-            const size_t o = frame * (size_t)a.max_kp + base + lane;
             // correct_keypoint_scale (:1166-1179): float multiply, skipped for level 0
-            a.xy[2 * o] = my_level == 0 ? fx : __fmul_rn(fx, scale);
-            a.xy[2 * o + 1] = my_level == 0 ? fy : __fmul_rn(fy, scale);
-            a.octave[o] = my_level;
-            a.angle[o] = angle;
-            a.response[o] = (float)kp_score(my_kp);
+            my_ox = my_level == 0 ? fx : __fmul_rn(fx, my_scale);
+            my_oy = my_level == 0 ? fy : __fmul_rn(fy, my_scale);
         }
 
         // ---- C. descriptors
@@ -279,28 +351,11 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
             // 16 (t + 64 q) of the patch — exactly row-major with a 64-byte pitch.  Three DMA instructions per
             // keypoint instead of seven register loads + seven LDS stores, and the patches of the next two
             // keypoints are in flight while one is sampled.
-            auto dma_patch = [&](int k, int buf) {
-                int px, py;
-                const LevelGeom& lv = kp_of(k, px, py);
-                const int bx0 = px - kPatchR;
-                const uint8_t* bsrc = blur + lv.offset + (py - kPatchR) * lv.pitch + (bx0 & ~15);
-                const uint32_t pitch = (uint32_t)lv.pitch;
-#pragma unroll
-                for(int q = 0; q < 3; ++q)
-                {
-                    const uint32_t t = (uint32_t)lane + 64u * q;
-                    if(t < (uint32_t)(kPatchRows * 4))
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(bsrc + __umul24(t >> 2, pitch) + 16u * (t & 3u)),
-                            (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
-                }
-            };
             auto describe = [&](int k, int buf) {
                 const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ca), k));
                 const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sa), k));
-                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)my_kp, k);
-                const int sh = (kp_x(p) + kBorder - kPatchR) & 15;
-                const uint8_t* bc =
+                const int sh = (int)(bc(my_sh, k) >> 4);
+                const uint8_t* ctr =
                     reinterpret_cast<const uint8_t*>(patch[wave][buf]) + kPatchR * (kPatchDw * 4) + kPatchR + sh; // centre
                 unsigned long long bits[4];
 #pragma unroll
@@ -312,8 +367,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(q.x, ca), __fmul_rn(q.y, sa)));
                     const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(q.z, sa), __fmul_rn(q.w, ca)));
                     const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(q.z, ca), __fmul_rn(q.w, sa)));
-                    const int v0 = bc[__mul24(r0, kPatchDw * 4) + c0];
-                    const int v1 = bc[__mul24(r1, kPatchDw * 4) + c1];
+                    const int v0 = ctr[__mul24(r0, kPatchDw * 4) + c0];
+                    const int v1 = ctr[__mul24(r1, kPatchDw * 4) + c1];
                     bits[t] = __ballot(v0 < v1);
                 }
                 if(lane < 4)
@@ -325,13 +380,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k) * 32)[lane] = w;
                 }
             };
-            constexpr int kDepth = kPatchBufs - 1; // patches in flight beside the one being sampled
             static_assert(kPatchBufs == 4, "phase A's vmcnt immediates are written for three windows in flight");
             static_assert(kDepth >= 1 && kDepth <= 5, "the vmcnt immediates below cover up to 5 patches in flight");
-#pragma unroll
-            for(int i = 0; i < kDepth; ++i)
-                if(i < n_here)
-                    dma_patch(i, i);
             for(int k = 0; k < n_here; ++k)
             {
                 // patch k must have landed: LDS-DMA is counted by vmcnt, in issue order, so "at most the DMAs issued
@@ -356,6 +406,14 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 describe(k, k % kPatchBufs);
                 __builtin_amdgcn_wave_barrier(); // the gathers are done before the slot is refilled
             }
+        }
+        if(lane < n_here)
+        {
+            const size_t o = frame * (size_t)a.max_kp + base + lane;
+            reinterpret_cast<float2*>(a.xy)[o] = make_float2(my_ox, my_oy);
+            a.octave[o] = my_level;
+            a.angle[o] = my_angle;
+            a.response[o] = (float)kp_score(my_kp);
         }
     }
 }
