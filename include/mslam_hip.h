@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSLAM_HIP_ABI_VERSION 1
+#define MSLAM_HIP_ABI_VERSION 2
 
 enum
 {
@@ -50,7 +50,24 @@ typedef struct
     int32_t max_candidates; /* per-(frame,level) FAST candidate capacity feeding the quadtree              */
     int32_t device;         /* HIP device ordinal                                                          */
     void* stream;           /* hipStream_t to enqueue on; NULL = the context creates its own               */
+    /* which of the reference's two IFeatureDetector implementations this context is a drop-in for: */
+    int32_t detector;       /* MSLAM_HIP_DETECTOR_DISTRIBUTED (default) or MSLAM_HIP_DETECTOR_CV_ORB               */
+    int32_t n_features;     /* CV_ORB: cv::ORB::create(nfeatures) (1000, orb_feature.cpp:25)                       */
+    int32_t edge_threshold; /* CV_ORB: edgeThreshold (31, cv::ORB default); FAST threshold = ini_fast_thr (20)      */
 } mslam_hip_params;
+
+enum
+{
+    /* DistributedOrbOpenCvDetector (distributed_cv_feature.cpp:1181-1222): 64-px FAST cells + quadtree, util::cos/sin */
+    MSLAM_HIP_DETECTOR_DISTRIBUTED = 0,
+    /* OrbOpenCvDetector (orb_feature.cpp:25,33-65): toGrayScale + cv::ORB::create(n)->detectAndCompute — INTER_LINEAR_EXACT
+     * pyramid, whole-level FAST, retainBest(2n) / Harris response / retainBest(n) per level, libm-style cos/sin.  Two
+     * documented deviations: keypoints of a level come in FAST raster order (the reference's order is what
+     * std::nth_element leaves behind: implementation-defined; the SET is the same), and cos/sin come from
+     * include/mslam_sincos.h (correctly rounded in practice) instead of the host libm's cosf/sinf.  n_levels,
+     * scale_factor, ini_fast_thr keep their meaning; min_fast_thr / min_node_area are unused. */
+    MSLAM_HIP_DETECTOR_CV_ORB = 1
+};
 
 void mslam_hip_default_params(mslam_hip_params* p);
 int mslam_hip_abi_version(void);

@@ -1,0 +1,64 @@
+/* mslam_sincos.h — the cos/sin used by the cv::ORB detector mode (orb_feature.cpp:25,40; OpenCV orb.cpp
+ * computeOrbDescriptors: `angle *= (float)(CV_PI/180.f); float a = (float)cos(angle), b = (float)sin(angle);`).
+ *
+ * The reference gets these two floats from the host C library (cosf / sinf), whose last-bit behaviour is not
+ * specified and differs between libm versions; a GPU cannot call it.  This routine evaluates cos / sin of the
+ * float angle in IEEE double arithmetic (Cody-Waite reduction to [-pi/4, pi/4], Taylor polynomials to r^16 / r^15:
+ * absolute error < 1e-15 for |x| <= 8) and rounds the result to float, i.e. it returns the correctly rounded
+ * float value except where the exact result lies within 1e-15 of a rounding boundary (about one argument in 1e8).
+ * Every operation is a single rounded double add / multiply / floor in a fixed order, so the host build
+ * (gcc -ffp-contract=off) and the device build (hipcc -ffp-contract=off) produce identical bits.
+ * tests/test_oracle_cv_orb.py measures how often this host's libm cosf / sinf differs from it.
+ */
+#ifndef MSLAM_SINCOS_H_
+#define MSLAM_SINCOS_H_
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define MSLAM_HD __host__ __device__ static inline
+#else
+#include <math.h>
+#define MSLAM_HD static inline
+#endif
+
+MSLAM_HD void mslam_sincos_f32(float xf, float* s_out, float* c_out)
+{
+    const double x = (double)xf;
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632679489655800e+00; /* pi/2 rounded to double            */
+    const double pio2_lo = 6.12323399573676603587e-17; /* pi/2 - pio2_hi                    */
+    const double kd = floor(x * two_over_pi + 0.5);
+    const int k = (int)kd;
+    const double r = (x - kd * pio2_hi) - kd * pio2_lo;
+    const double z = r * r;
+    /* sin r = r (1 - z/3! + z^2/5! - ... - z^7/15!),  cos r = 1 - z/2! + z^2/4! - ... + z^8/16! */
+    double ps = -1.0 / 1307674368000.0;
+    ps = ps * z + 1.0 / 6227020800.0;
+    ps = ps * z - 1.0 / 39916800.0;
+    ps = ps * z + 1.0 / 362880.0;
+    ps = ps * z - 1.0 / 5040.0;
+    ps = ps * z + 1.0 / 120.0;
+    ps = ps * z - 1.0 / 6.0;
+    ps = ps * z + 1.0;
+    const double s = ps * r;
+    double pc = 1.0 / 20922789888000.0;
+    pc = pc * z - 1.0 / 87178291200.0;
+    pc = pc * z + 1.0 / 479001600.0;
+    pc = pc * z - 1.0 / 3628800.0;
+    pc = pc * z + 1.0 / 40320.0;
+    pc = pc * z - 1.0 / 720.0;
+    pc = pc * z + 1.0 / 24.0;
+    pc = pc * z - 0.5;
+    const double c = pc * z + 1.0;
+    double sr, cr;
+    switch(k & 3)
+    {
+    case 0: sr = s, cr = c; break;
+    case 1: sr = c, cr = -s; break;
+    case 2: sr = -s, cr = -c; break;
+    default: sr = -c, cr = s; break;
+    }
+    *s_out = (float)sr;
+    *c_out = (float)cr;
+}
+
+#endif /* MSLAM_SINCOS_H_ */

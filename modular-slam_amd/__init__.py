@@ -26,6 +26,7 @@ LIB_PATH = os.path.join(_HERE, "libmslam_hip.so")
 OK, E_INVALID, E_RUNTIME, E_CAPACITY, E_NO_VOCABULARY, E_FORMAT = range(6)
 DBG_PYRAMID, DBG_BLURRED, DBG_CANDIDATES, DBG_SELECTED = range(4)
 MATCHER_AUTO, MATCHER_POPCOUNT = 0, 1
+DETECTOR_DISTRIBUTED, DETECTOR_CV_ORB = 0, 1
 
 # every symbol include/mslam_hip.h declares (tests/test_cabi.py checks the .so exports them all)
 ABI_SYMBOLS = [
@@ -52,7 +53,8 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32), ("n_levels", C.c_int32),
                 ("scale_factor", C.c_float), ("ini_fast_thr", C.c_int32), ("min_fast_thr", C.c_int32),
                 ("min_node_area", C.c_uint32), ("max_keypoints", C.c_int32), ("max_candidates", C.c_int32),
-                ("device", C.c_int32), ("stream", C.c_void_p)]
+                ("device", C.c_int32), ("stream", C.c_void_p), ("detector", C.c_int32), ("n_features", C.c_int32),
+                ("edge_threshold", C.c_int32)]
 
 
 class BatchView(C.Structure):

@@ -251,10 +251,94 @@ static int build_geometry(mslam_hip_ctx* c)
     return MSLAM_HIP_OK;
 }
 
+// cv::ORB mode geometry (OpenCV orb.cpp): layerScale[l] = (float)pow(scaleFactor, l) with the double member holding
+// the float argument; sizes cvRound(cols * (1.0f / scale)) in float; nfeaturesPerLevel as computeKeyPoints does.
+static int build_geometry_cv(mslam_hip_ctx* c)
+{
+    const mslam_hip_params& p = c->p;
+    Geometry& g = c->geom;
+    g.n_levels = p.n_levels;
+    g.W = p.width;
+    g.H = p.height;
+    const double sf = (double)p.scale_factor;
+    unsigned offset = 0;
+    int n_strips = 0;
+    c->cells.clear();
+    for(int l = 0; l < p.n_levels; ++l)
+    {
+        LevelGeom& lv = g.lv[l];
+        lv = LevelGeom{};
+        lv.scale = (float)std::pow(sf, (double)l);
+        const float inv = 1.0f / lv.scale;
+        lv.w = cv_round_f((float)p.width * inv);
+        lv.h = cv_round_f((float)p.height * inv);
+        if(lv.w < 16 || lv.h < 16)
+            return fail(c, MSLAM_HIP_E_INVALID, "pyramid level " + std::to_string(l) + " is smaller than 16 px");
+        if(lv.w > 4095 || lv.h > 4095)
+            return fail(c, MSLAM_HIP_E_INVALID, "frames larger than 4095 px per side are not supported");
+        lv.pitch = (lv.w + 15) & ~15;
+        lv.offset = (int)offset;
+        offset += ((unsigned)lv.pitch * lv.h + 255u) & ~255u;
+        lv.bw = lv.w - 2 * kBorder;
+        lv.bh = lv.h - 2 * kBorder;
+        lv.bsx = (lv.w + 3) / 4;
+        lv.tile_base = n_strips;
+        lv.n_tiles = lv.bsx * ((lv.h + kBlurRows - 1) / kBlurRows);
+        n_strips += lv.n_tiles;
+    }
+    g.slab = offset + 256;
+    g.n_cells = 0;
+    g.n_tiles = n_strips;
+    const float factor = (float)(1.0 / sf);
+    float desired = (float)p.n_features * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.n_levels));
+    int sum = 0;
+    for(int l = 0; l < p.n_levels - 1; ++l)
+    {
+        c->cv_quota[l] = cv_round_f(desired);
+        sum += c->cv_quota[l];
+        desired *= factor;
+    }
+    c->cv_quota[p.n_levels - 1] = std::max(p.n_features - sum, 0);
+    return MSLAM_HIP_OK;
+}
+
+// interpolationLinear<uchar>::getCoeffs (imgproc resize.cpp): offsets, 8.8 coefficients, interpolating range
+static void exact_axis(int ssize, int dsize, std::vector<int32_t>& ofs, std::vector<uint32_t>& coef, int& dmin, int& dmax)
+{
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    dmin = 0;
+    dmax = dsize;
+    for(int d = 0; d < dsize; ++d)
+    {
+        const double fval = scale * ((double)d + 0.5) - 0.5;
+        const int ival = (int)std::floor(fval);
+        int o = 0;
+        uint32_t c0 = 256, c1 = 0;
+        if(ival >= 0 && ssize > 1)
+        {
+            if(ival < ssize - 1)
+            {
+                o = ival;
+                c1 = (uint32_t)lrint((fval - (double)ival) * 256.0);
+                c0 = 256 - c1;
+            }
+            else
+            {
+                o = ssize - 1;
+                dmax = std::min(dmax, d);
+            }
+        }
+        else
+            dmin = std::max(dmin, d + 1);
+        ofs.push_back(o);
+        coef.push_back(c0 | (c1 << 16));
+    }
+}
+
 template <typename T>
 static hipError_t dmalloc(T*& p, size_t n)
 {
-    return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+    return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(T));
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------
@@ -275,6 +359,9 @@ void mslam_hip_default_params(mslam_hip_params* p)
     p->max_candidates = 16384;
     p->device = 0;
     p->stream = nullptr;
+    p->detector = MSLAM_HIP_DETECTOR_DISTRIBUTED;
+    p->n_features = 1000;    // orb_feature.cpp:25
+    p->edge_threshold = 31;  // cv::ORB::create default
 }
 
 int mslam_hip_abi_version(void) { return MSLAM_HIP_ABI_VERSION; }
@@ -288,7 +375,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
     if(c->stream)
         (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_rs_qt, c->d_ratio_thr, c->d_orient_w, c->d_stage,  c->d_pyr,
-                    c->d_blur,    c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
+                    c->d_blur,    c->d_cv_ofs, c->d_cv_coef, c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_to, c->d_hm_out,
                     c->d_xyz, c->d_valid};
@@ -357,6 +444,11 @@ static int create_impl(mslam_hip_ctx* c)
        p.min_fast_thr > p.ini_fast_thr || p.max_keypoints < 1 || p.max_keypoints > 65535 || p.max_candidates < 1 ||
        p.max_candidates > (1 << 22))
         return fail(c, MSLAM_HIP_E_INVALID, "invalid parameters");
+    const bool cv_mode = p.detector == MSLAM_HIP_DETECTOR_CV_ORB;
+    if((p.detector != MSLAM_HIP_DETECTOR_DISTRIBUTED && !cv_mode) ||
+       (cv_mode && (p.n_features < 0 || p.edge_threshold < 19 || p.edge_threshold > 1024)))
+        return fail(c, MSLAM_HIP_E_INVALID, "invalid detector parameters (cv::ORB mode needs edge_threshold >= 19: "
+                                            "the descriptor pattern reaches 19 px)");
     int umax[16];
     if(!umax_table(umax))
         return fail(c, MSLAM_HIP_E_INVALID, "u_max table self-check failed");
@@ -367,7 +459,7 @@ static int create_impl(mslam_hip_ctx* c)
         return fail(c, MSLAM_HIP_E_INVALID, "gaussian tap self-check failed");
     set_blur_taps(taps);
 
-    int rc = has_detector ? build_geometry(c) : MSLAM_HIP_OK;
+    int rc = !has_detector ? MSLAM_HIP_OK : cv_mode ? build_geometry_cv(c) : build_geometry(c);
     if(rc)
         return rc;
     const Geometry& g = c->geom;
@@ -397,7 +489,28 @@ static int create_impl(mslam_hip_ctx* c)
         }
     }
     // tables
-    if(has_detector)
+    if(has_detector && cv_mode)
+    {
+        std::vector<int32_t> ofs;
+        std::vector<uint32_t> coef;
+        c->cv_x.assign(p.n_levels, 0);
+        c->cv_y.assign(p.n_levels, 0);
+        c->cv_range.assign(p.n_levels, std::array<int, 4>{0, 0, 0, 0});
+        for(int l = 1; l < p.n_levels; ++l)
+        {
+            c->cv_x[l] = ofs.size();
+            exact_axis(g.lv[l - 1].w, g.lv[l].w, ofs, coef, c->cv_range[l][0], c->cv_range[l][1]);
+            c->cv_y[l] = ofs.size();
+            exact_axis(g.lv[l - 1].h, g.lv[l].h, ofs, coef, c->cv_range[l][2], c->cv_range[l][3]);
+        }
+        ofs.push_back(0);
+        coef.push_back(0);
+        HIPCHK(c, dmalloc(c->d_cv_ofs, ofs.size()));
+        HIPCHK(c, dmalloc(c->d_cv_coef, coef.size()));
+        HIPCHK(c, hipMemcpy(c->d_cv_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_cv_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
+    }
+    if(has_detector && !cv_mode)
     {
     HIPCHK(c, dmalloc(c->d_cells, c->cells.size()));
     HIPCHK(c, hipMemcpy(c->d_cells, c->cells.data(), c->cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
@@ -618,6 +731,52 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             StageScope t(c, "gray", cs);
             launch_gray(d_bgr, c->d_pyr, g, f0, nf, cs);
         }
+        const bool cv_mode = c->p.detector == MSLAM_HIP_DETECTOR_CV_ORB;
+        if(cv_mode)
+        {
+            // OrbOpenCvDetector (orb_feature.cpp:33-65 -> OpenCV orb.cpp detectAndCompute), see k_cvorb.hip
+            {
+                StageScope t(c, "resize", cs);
+                for(int l = 1; l < g.n_levels; ++l)
+                {
+                    const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
+                    ExactResizeArgs ra{};
+                    ra.pyr = c->d_pyr;
+                    ra.slab = g.slab;
+                    ra.src_off = sl.offset, ra.sw = sl.w, ra.sh = sl.h, ra.spitch = sl.pitch;
+                    ra.dst_off = dl.offset, ra.dw = dl.w, ra.dh = dl.h, ra.dpitch = dl.pitch;
+                    ra.xofs = c->d_cv_ofs + c->cv_x[l];
+                    ra.xcoef = c->d_cv_coef + c->cv_x[l];
+                    ra.yofs = c->d_cv_ofs + c->cv_y[l];
+                    ra.ycoef = c->d_cv_coef + c->cv_y[l];
+                    ra.xmin = c->cv_range[l][0], ra.xmax = c->cv_range[l][1];
+                    ra.ymin = c->cv_range[l][2], ra.ymax = c->cv_range[l][3];
+                    ra.frame0 = f0;
+                    launch_resize_exact(ra, nf, cs);
+                }
+            }
+            CvSelectArgs sa{};
+            sa.cand = c->quad.cand, sa.cand_cnt = c->quad.cand_cnt;
+            sa.tmp_kp = c->quad.kp_node, sa.tmp_resp = reinterpret_cast<float*>(c->quad.ninfo);
+            sa.sel = c->quad.sel, sa.sel_resp = reinterpret_cast<float*>(c->quad.best), sa.sel_cnt = c->quad.sel_cnt;
+            sa.flags = c->d_flags;
+            sa.cand_cap = c->p.max_candidates;
+            sa.edge = c->p.edge_threshold;
+            for(int l = 0; l < g.n_levels; ++l)
+                sa.quota[l] = c->cv_quota[l];
+            {
+                // the FAST score plane lives in the blur slab until the blur (which comes last) overwrites it
+                StageScope t(c, "fast", cs);
+                for(int l = 0; l < g.n_levels; ++l)
+                    launch_fast_score(c->d_pyr, c->d_blur, g, l, c->p.ini_fast_thr, f0, nf, cs);
+            }
+            {
+                StageScope t(c, "select", cs);
+                launch_cv_select(c->d_pyr, c->d_blur, g, sa, f0, nf, cs);
+            }
+        }
+        else
+        {
         {
             StageScope t(c, "resize", cs);
             for(int l = 1; l < g.n_levels; ++l)
@@ -660,6 +819,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             StageScope t(c, "quadtree", cs);
             launch_quadtree(g, c->quad, f0, nf, cs);
         }
+        } // in-tree detector
         {
             StageScope t(c, "blur", cs);
             launch_blur(c->d_pyr, c->d_blur, g, f0, nf, cs);
@@ -681,6 +841,11 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             a.response = c->d_response + K;
             a.count = c->d_count + 1;
             a.flags = c->d_flags;
+            if(cv_mode)
+            {
+                a.sel_resp = reinterpret_cast<const float*>(c->quad.best);
+                a.cv_mode = 1;
+            }
             launch_describe(g, a, f0, nf, cs);
         }
         if(n_chunks > 1)
@@ -1150,6 +1315,21 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
             out[3 * i] = (float)kp_x(tmp[i]);
             out[3 * i + 1] = (float)kp_y(tmp[i]);
             out[3 * i + 2] = (float)kp_score(tmp[i]);
+        }
+        if(c->p.detector == MSLAM_HIP_DETECTOR_CV_ORB && !cand)
+        {
+            // cv::ORB mode: absolute level coordinates (the list is kept relative to (19, 19) for k_describe) and the
+            // Harris response
+            std::vector<float> resp(n);
+            if(n)
+                HIPCHK(c, hipMemcpy(resp.data(), reinterpret_cast<const float*>(c->quad.best) + slot * (size_t)c->p.max_candidates,
+                                    (size_t)n * 4, hipMemcpyDeviceToHost));
+            for(uint32_t i = 0; i < n; ++i)
+            {
+                out[3 * i] += (float)kBorder;
+                out[3 * i + 1] += (float)kBorder;
+                out[3 * i + 2] = resp[i];
+            }
         }
         return MSLAM_HIP_OK;
     }

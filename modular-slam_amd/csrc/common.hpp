@@ -128,8 +128,46 @@ struct DescArgs
     int32_t* count;
     uint32_t* flags;
     int n_frames = 0; // filled in by the launcher
+    // cv::ORB mode (orb_feature.cpp:25 -> OpenCV orb.cpp): the keypoint response is the Harris response of the
+    // selection kernel, and cos / sin of the angle follow computeOrbDescriptors (float degree -> radian product,
+    // include/mslam_sincos.h in place of the host libm) instead of the in-tree util::cos / util::sin
+    const float* sel_resp = nullptr; // [B][L][cand_cap], parallel to sel
+    int cv_mode = 0;
 };
 void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_frames, hipStream_t s);
+
+// ---- cv::ORB detector mode (k_cvorb.hip) ----------------------------------------------------------------------
+struct ExactResizeArgs
+{
+    uint8_t* pyr;
+    unsigned slab;
+    int src_off, sw, sh, spitch, dst_off, dw, dh, dpitch;
+    const int32_t* xofs;   // [dw]
+    const uint32_t* xcoef; // [dw] c0 | c1 << 16 (8.8 fixed point, c0 + c1 = 256)
+    const int32_t* yofs;   // [dh]
+    const uint32_t* ycoef; // [dh]
+    int xmin, xmax, ymin, ymax; // destination positions outside [min, max) copy the first / last source sample
+    int frame0;
+};
+void launch_resize_exact(const ExactResizeArgs& a, int n_frames, hipStream_t s);
+void launch_fast_score(const uint8_t* d_pyr, uint8_t* d_plane, const Geometry& g, int level, int thr, int frame0,
+                       int n_frames, hipStream_t s);
+struct CvSelectArgs
+{
+    uint32_t* cand;     // [B][L][cand_cap] FAST keypoints after NMS + border filter, raster order, ABSOLUTE coordinates
+    uint32_t* cand_cnt; // [B][L]
+    uint32_t* tmp_kp;   // [B][L][cand_cap] scratch
+    float* tmp_resp;    // [B][L][cand_cap] scratch
+    uint32_t* sel;      // [B][L][cand_cap] final keypoints, coordinates relative to (19, 19) (k_describe's convention)
+    float* sel_resp;    // [B][L][cand_cap] Harris responses
+    uint32_t* sel_cnt;  // [B][L]
+    uint32_t* flags;
+    int cand_cap;
+    int edge;           // edgeThreshold (31)
+    int quota[kMaxLevels]; // nfeaturesPerLevel
+};
+void launch_cv_select(const uint8_t* d_pyr, const uint8_t* d_plane, const Geometry& g, const CvSelectArgs& a, int frame0,
+                      int n_frames, hipStream_t s);
 
 // knn-2 Hamming match for `n_pairs` independent (from, to) pairs.  Descriptor sets are addressed as
 // base + pair_index * stride; counts come from device arrays (or fixed values when the pointer is null).

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.hpp"
 #include "../../include/mslam_hip.h"
+#include <array>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,12 @@ struct mslam_hip_ctx
     uint4* d_rs_qt = nullptr;       // quad tables (k_resize_col), all levels, 3 x uint4 per quad
     std::vector<size_t> rs_q;       // per-level start (in quads) into the quad tables; SIZE_MAX = use the generic kernel
     std::vector<int> rs_need;       // per level: which pixel positions of a quad ever use the upper dword pair
+    // cv::ORB mode: INTER_LINEAR_EXACT tables (all levels) and per-level quota
+    int32_t* d_cv_ofs = nullptr;
+    uint32_t* d_cv_coef = nullptr;
+    std::vector<size_t> cv_x, cv_y;           // per-level start index into d_cv_*
+    std::vector<std::array<int, 4>> cv_range; // per level: xmin, xmax, ymin, ymax
+    int cv_quota[mslam::kMaxLevels] = {0};
     int32_t* d_ratio_thr = nullptr; // [257]
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
     hipGraphExec_t detect_graph[2] = {nullptr, nullptr}; // mslam_hip_detect's kernel + copy sequence, per output set

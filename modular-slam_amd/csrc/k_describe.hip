@@ -10,6 +10,7 @@
 // the reference expression order; cvRound = round-half-even, cvFloor = floor.
 #include "common.hpp"
 #include "../../include/mslam_orb_pattern.h"
+#include "../../include/mslam_sincos.h"
 
 namespace mslam
 {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
         uint32_t my_kp = 0;
         int my_level = 0;
         uint32_t my_doff = 0, my_poff = 0, my_pitch = 16, my_sh = 0;
-        float my_scale = 1.f;
+        float my_scale = 1.f, my_resp = 0.f;
         {
             const int idx = base + lane; // position in the frame's concatenated keypoint list (:787-808)
             int first = 0;               // list position of the level's first keypoint
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
             }
             if(lane < n_here)
             {
-                my_kp = a.sel[(frame * g.n_levels + my_level) * (size_t)a.cand_cap + my_kp];
+                const size_t si = (frame * g.n_levels + my_level) * (size_t)a.cand_cap + my_kp;
+                my_kp = a.sel[si];
+                my_resp = a.sel_resp ? a.sel_resp[si] : (float)kp_score(my_kp);
                 const int px = kp_x(my_kp) + kBorder, py = kp_y(my_kp) + kBorder; // :966-967
                 my_doff = lofs + (uint32_t)(py - 15) * my_pitch + (uint32_t)((px - 15) & ~15);
                 my_poff = lofs + (uint32_t)(py - kPatchR) * my_pitch + (uint32_t)((px - kPatchR) & ~15);
@@ -334,12 +337,21 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
         if(lane < n_here)
         {
             my_angle = fast_atan2_deg((float)my_m01, (float)my_m10);
-            const float rad = (float)((double)my_angle * 3.14159265358979323846 / 180.0); // :574
-            my_ca = util_cos(rad);
-            my_sa = util_sin(rad);
+            if(a.cv_mode)
+            {
+                // orb.cpp computeOrbDescriptors: angle *= (float)(CV_PI/180.f); a = (float)cos(angle), b = (float)sin(angle)
+                const float rad = __fmul_rn(my_angle, (float)(3.1415926535897932384626433832795 / 180.f));
+                mslam_sincos_f32(rad, &my_sa, &my_ca);
+            }
+            else
+            {
+                const float rad = (float)((double)my_angle * 3.14159265358979323846 / 180.0); // :574
+                my_ca = util_cos(rad);
+                my_sa = util_sin(rad);
+            }
             const float fx = (float)(kp_x(my_kp) + kBorder), fy = (float)(kp_y(my_kp) + kBorder);
             // correct_keypoint_scale (:1166-1179): float multiply, skipped for level 0
-            my_ox = my_level == 0 ? fx : __fmul_rn(fx, my_scale);
+            my_ox = my_level == 0 ? fx : __fmul_rn(fx, my_scale); // (cv mode: level 0 has scale 1.0f, same result)
             my_oy = my_level == 0 ? fy : __fmul_rn(fy, my_scale);
         }
 
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
             reinterpret_cast<float2*>(a.xy)[o] = make_float2(my_ox, my_oy);
             a.octave[o] = my_level;
             a.angle[o] = my_angle;
-            a.response[o] = (float)kp_score(my_kp);
+            a.response[o] = my_resp;
         }
     }
 }

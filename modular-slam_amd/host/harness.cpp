@@ -37,7 +37,11 @@ int main(int argc, char** argv)
     }
     try
     {
-        auto makeDetector = mslam::loadFactoryMethod<mslam::IOrbFeatureDetector>(argv[1], "hipOrbDetectorFactory");
+        // MSLAM_HARNESS_DETECTOR=cvorb: the factory of the OrbOpenCvDetector drop-in instead of the in-tree extractor's
+        const char* det = std::getenv("MSLAM_HARNESS_DETECTOR");
+        const bool cvorb = det && std::strcmp(det, "cvorb") == 0;
+        auto makeDetector = mslam::loadFactoryMethod<mslam::IOrbFeatureDetector>(
+            argv[1], cvorb ? "hipCvOrbDetectorFactory" : "hipOrbDetectorFactory");
         auto makeMatcher = mslam::loadFactoryMethod<mslam::IOrbMatcher>(argv[1], "hipOrbMatcherFactory");
         if(!makeDetector || !makeMatcher)
             return 3;

@@ -2,7 +2,9 @@
 // and the factory aliases the reference's loader imports.
 //
 //   HipOrbDetector    : IFeatureDetector<RgbFrame,u8,32>   drop-in for DistributedOrbOpenCvDetector
-//                                                           (distributed_cv_feature.cpp:1181-1222)
+//                                                           (distributed_cv_feature.cpp:1181-1222) and, created by
+//                                                           hipCvOrbDetectorFactory, for OrbOpenCvDetector
+//                                                           (orb_feature.cpp:25,33-65: the cv::ORB mode)
 //   HipOrbMatcher     : IFeatureMatcher<u8,32>             drop-in for OrbOpenCvMatcher (orb_feature.cpp:84-130)
 //   HipOrbRelocalizer : IRelocalizer                       what OrbRelocalizer is wired for
 //                                                           (orb_relocalizer.cpp:26-50, rgbd_feature_frontend.cpp:153,176)
@@ -43,6 +45,7 @@ struct Ctx
     mslam_hip_ctx* h = nullptr;
     int width = -1, height = -1, capacity = 0;
     // width = height = 0: a context without detector buffers (the matcher and the BoW database need none)
+    int detector = MSLAM_HIP_DETECTOR_DISTRIBUTED;
     void ensure(int w, int h_, int max_keypoints = 0)
     {
         if(h && w == width && h_ == height && (max_keypoints == 0 || max_keypoints == capacity))
@@ -54,6 +57,7 @@ struct Ctx
         mslam_hip_default_params(&p); // the reference's hard-coded operating point
         p.width = w;
         p.height = h_;
+        p.detector = detector;
         if(max_keypoints > 0)
         {
             p.max_keypoints = max_keypoints;
@@ -84,6 +88,7 @@ void gather_descriptors(const std::vector<OrbKeypoint>& kps, std::vector<std::ui
 class HipOrbDetector : public IOrbFeatureDetector
 {
   public:
+    explicit HipOrbDetector(int detector = MSLAM_HIP_DETECTOR_DISTRIBUTED) { ctx.detector = detector; }
     std::vector<OrbKeypoint> detect(const RgbFrame& sensorData) override
     {
         std::vector<OrbKeypoint> result;
@@ -294,6 +299,12 @@ class HipLoopDetector : public IOrbLoopDetector
 
 // ---- factories + aliases (what loadFactoryMethod<T>(lib, name) imports) -------------------------------
 std::unique_ptr<IOrbFeatureDetector> createHipOrbDetector() { return std::make_unique<HipOrbDetector>(); }
+// drop-in for OrbOpenCvDetector (orb_feature.cpp:25,33-65; wired by src/app/slam/rgbd_slam.cpp:74-76).  The reference leaves
+// Keypoint::id uninitialised there (orb_feature.cpp:54-61); the running index is used instead.
+std::unique_ptr<IOrbFeatureDetector> createHipCvOrbDetector()
+{
+    return std::make_unique<HipOrbDetector>(MSLAM_HIP_DETECTOR_CV_ORB);
+}
 std::unique_ptr<IOrbMatcher> createHipOrbMatcher() { return std::make_unique<HipOrbMatcher>(); }
 std::unique_ptr<IOrbRelocalizer> createHipOrbRelocalizer() { return std::make_unique<HipOrbRelocalizer>(); }
 std::unique_ptr<IOrbLoopDetector> createHipLoopDetector() { return std::make_unique<HipLoopDetector>(); }
@@ -301,6 +312,7 @@ std::unique_ptr<IOrbLoopDetector> createHipLoopDetector() { return std::make_uni
 } // namespace mslam
 
 MSLAM_DLL_ALIAS(mslam::createHipOrbDetector, hipOrbDetectorFactory)
+MSLAM_DLL_ALIAS(mslam::createHipCvOrbDetector, hipCvOrbDetectorFactory)
 MSLAM_DLL_ALIAS(mslam::createHipOrbMatcher, hipOrbMatcherFactory)
 MSLAM_DLL_ALIAS(mslam::createHipOrbRelocalizer, hipOrbRelocalizerFactory)
 MSLAM_DLL_ALIAS(mslam::createHipLoopDetector, loopDetection) // key used by test/plugin_config.json

@@ -1147,3 +1147,273 @@ double mso_bow_score_l1(const uint32_t* w1, const double* v1, int n1, const uint
     }
     return -score / 2.0;
 }
+
+/* ==== cv::ORB detector mode (orb_feature.cpp:25,33-65 -> OpenCV 4.8.1 features2d/src/orb.cpp) ================ */
+#include "../include/mslam_sincos.h"
+
+void mso_cvorb_default_params(mso_cvorb_params* p)
+{
+    p->n_features = 1000; /* orb_feature.cpp:25 */
+    p->scale_factor = 1.2f;
+    p->n_levels = 8;
+    p->edge_threshold = 31;
+    p->fast_threshold = 20;
+}
+
+/* orb.cpp: getScale(level, firstLevel = 0, scaleFactor) = (float)std::pow(scaleFactor, (double)level) with the
+ * double member scaleFactor holding the float argument of ORB::create; sizes in detectAndCompute:
+ * cvRound(cols * inv_scale), inv_scale = 1.0f / scale (float arithmetic); quota in computeKeyPoints. */
+void mso_cvorb_geometry(int W, int H, const mso_cvorb_params* p, int* w, int* h, float* scale, int* quota)
+{
+    const double sf = (double)p->scale_factor;
+    for(int l = 0; l < p->n_levels; ++l)
+    {
+        scale[l] = (float)pow(sf, (double)l);
+        const float inv = 1.0f / scale[l];
+        w[l] = cv_round_f((float)W * inv);
+        h[l] = cv_round_f((float)H * inv);
+    }
+    const float factor = (float)(1.0 / sf);
+    float desired = (float)p->n_features * (1 - factor) / (1 - (float)pow((double)factor, (double)p->n_levels));
+    int sum = 0;
+    for(int l = 0; l < p->n_levels - 1; ++l)
+    {
+        quota[l] = cv_round_f(desired);
+        sum += quota[l];
+        desired *= factor;
+    }
+    quota[p->n_levels - 1] = p->n_features - sum > 0 ? p->n_features - sum : 0;
+}
+
+/* interpolationLinear<uchar>::getCoeffs (resize.cpp): offsets, 8.8 coefficients (ufixedpoint16), and the range
+ * [dmin, dmax) of destination positions that interpolate; positions outside copy the first / last source sample */
+static void exact_axis(int ssize, int dsize, int* ofs, uint16_t* c0, uint16_t* c1, int* dmin, int* dmax)
+{
+    const double scale = 1.0 / ((double)dsize / (double)ssize); /* softdouble::one() / softdouble(inv_scale) */
+    int mn = 0, mx = dsize;
+    for(int d = 0; d < dsize; ++d)
+    {
+        const double fval = scale * ((double)d + 0.5) - 0.5;
+        const int ival = (int)floor(fval);
+        ofs[d] = 0, c0[d] = 256, c1[d] = 0;
+        if(ival >= 0 && ssize > 1)
+        {
+            if(ival < ssize - 1)
+            {
+                ofs[d] = ival;
+                c1[d] = (uint16_t)cv_round_d((fval - (double)ival) * 256.0); /* ufixedpoint16(softdouble) */
+                c0[d] = (uint16_t)(256 - c1[d]);
+            }
+            else
+            {
+                ofs[d] = ssize - 1;
+                if(d < mx)
+                    mx = d;
+            }
+        }
+        else if(d + 1 > mn)
+            mn = d + 1;
+    }
+    *dmin = mn;
+    *dmax = mx;
+}
+
+void mso_resize_linear_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh)
+{
+    int* xo = (int*)malloc(sizeof(int) * (size_t)(dw + dh));
+    int* yo = xo + dw;
+    uint16_t* xc0 = (uint16_t*)malloc(sizeof(uint16_t) * 2 * (size_t)(dw + dh));
+    uint16_t *xc1 = xc0 + dw, *yc0 = xc1 + dw, *yc1 = yc0 + dh;
+    int xmin, xmax, ymin, ymax;
+    exact_axis(sw, dw, xo, xc0, xc1, &xmin, &xmax);
+    exact_axis(sh, dh, yo, yc0, yc1, &ymin, &ymax);
+    uint16_t* line0 = (uint16_t*)malloc(sizeof(uint16_t) * 2 * (size_t)dw);
+    uint16_t* line1 = line0 + dw;
+    for(int y = 0; y < dh; ++y)
+    {
+        /* hlineResizeCn<uchar, ufixedpoint16, 2, true, 1>: 8.8 values; left / right of the range = edge sample */
+        const int r0 = y < ymin ? 0 : (y >= ymax ? sh - 1 : yo[y]);
+        const int two = y >= ymin && y < ymax;
+        for(int k = 0; k <= two; ++k)
+        {
+            const uint8_t* s = src + (size_t)(r0 + k) * sw;
+            uint16_t* ln = k ? line1 : line0;
+            for(int x = 0; x < dw; ++x)
+            {
+                if(x < xmin)
+                    ln[x] = (uint16_t)(s[0] << 8);
+                else if(x >= xmax)
+                    ln[x] = (uint16_t)(s[sw - 1] << 8);
+                else
+                    ln[x] = (uint16_t)(xc0[x] * s[xo[x]] + xc1[x] * s[xo[x] + 1]);
+            }
+        }
+        uint8_t* d = dst + (size_t)y * dw;
+        for(int x = 0; x < dw; ++x)
+        {
+            if(two) /* vlineResize<uchar, ufixedpoint16, 2>: 16.16 sum, (v + 2^15) >> 16 */
+                d[x] = (uint8_t)(((uint32_t)line0[x] * yc0[y] + (uint32_t)line1[x] * yc1[y] + 32768u) >> 16);
+            else /* vlineSet: ufixedpoint16 -> uchar = (v + 128) >> 8 */
+                d[x] = (uint8_t)((line0[x] + 128u) >> 8);
+        }
+    }
+    free(line0);
+    free(xc0);
+    free(xo);
+}
+
+/* orb.cpp HarrisResponses: 7x7 block of 3x3 Sobel-like gradients, integer sums, float response */
+float mso_harris_response(const uint8_t* img, int step, int x, int y)
+{
+    const float harris_k = 0.04f;
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    int a = 0, b = 0, c = 0;
+    for(int i = -3; i <= 3; ++i)
+        for(int j = -3; j <= 3; ++j)
+        {
+            const uint8_t* p = img + (size_t)(y + i) * step + (x + j);
+            const int Ix = (p[1] - p[-1]) * 2 + (p[-step + 1] - p[-step - 1]) + (p[step + 1] - p[step - 1]);
+            const int Iy = (p[step] - p[-step]) * 2 + (p[step - 1] - p[-step - 1]) + (p[step + 1] - p[-step + 1]);
+            a += Ix * Ix;
+            b += Iy * Iy;
+            c += Ix * Iy;
+        }
+    return ((float)a * b - (float)c * c - harris_k * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+}
+
+/* orb.cpp computeOrbDescriptors, WTA_K == 2 */
+void mso_cvorb_descriptor(const uint8_t* blurred, int step, int x, int y, float angle_deg, uint8_t* desc)
+{
+    float angle = angle_deg;
+    angle *= (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    mslam_sincos_f32(angle, &b, &a); /* a = cos, b = sin (the reference: host cosf / sinf) */
+    const uint8_t* center = blurred + (size_t)y * step + x;
+#define CV_VALUE(s)                                                                                                    \
+    (center[cv_round_f((float)k_pattern[(s)] * b + (float)k_pattern[(s) + 1] * a) * step +                            \
+            cv_round_f((float)k_pattern[(s)] * a - (float)k_pattern[(s) + 1] * b)])
+    for(int i = 0; i < 32; ++i)
+    {
+        int val = 0;
+        for(int k = 0; k < 8; ++k)
+        {
+            const int s = i * 32 + k * 4;
+            val |= (CV_VALUE(s) < CV_VALUE(s + 2)) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+#undef CV_VALUE
+}
+
+/* KeyPointsFilter::retainBest as a SET: keep every element whose response is >= the n-th largest (ties kept);
+ * stable (raster order preserved).  Returns the new count. */
+static int retain_best(mso_cand* kp, int n, int n_points)
+{
+    if(n_points < 0 || n <= n_points)
+        return n;
+    if(n_points == 0)
+        return 0;
+    float* r = (float*)malloc(sizeof(float) * (size_t)n);
+    for(int i = 0; i < n; ++i)
+        r[i] = kp[i].response;
+    /* n-th largest by selection (n is a few thousand at most) */
+    for(int i = 0; i < n_points; ++i)
+    {
+        int m = i;
+        for(int j = i + 1; j < n; ++j)
+            if(r[j] > r[m])
+                m = j;
+        const float t = r[i];
+        r[i] = r[m];
+        r[m] = t;
+    }
+    const float thr = r[n_points - 1];
+    free(r);
+    int k = 0;
+    for(int i = 0; i < n; ++i)
+        if(kp[i].response >= thr)
+            kp[k++] = kp[i];
+    return k;
+}
+
+int mso_cvorb_level_keypoints(const uint8_t* img, int w, int h, const mso_cvorb_params* p, int quota, int stage,
+                              mso_cand* out, int cap)
+{
+    /* FastFeatureDetector(fastThreshold, true)->detect on the level; runByImageBorder(edgeThreshold) */
+    int n = mso_fast(img, w, w, h, p->fast_threshold, out, cap);
+    int k = 0;
+    const int e = p->edge_threshold;
+    for(int i = 0; i < n; ++i)
+        if(out[i].x >= (float)e && out[i].x < (float)(w - e) && out[i].y >= (float)e && out[i].y < (float)(h - e))
+            out[k++] = out[i];
+    n = retain_best(out, k, 2 * quota); /* HARRIS_SCORE: keep 2x, orb.cpp computeKeyPoints */
+    if(stage == 0)
+        return n;
+    for(int i = 0; i < n; ++i)
+        out[i].response = mso_harris_response(img, w, cv_round_f(out[i].x), cv_round_f(out[i].y));
+    return retain_best(out, n, quota);
+}
+
+int mso_cvorb_detect(const uint8_t* bgr, int W, int H, const mso_cvorb_params* p, int max_out, float* xy, uint8_t* desc,
+                     int32_t* octave, float* angle, float* response, int* n_out)
+{
+    *n_out = 0;
+    if(W <= 0 || H <= 0 || p->n_levels < 1 || p->n_levels > MSO_MAX_LEVELS)
+        return 0;
+    int w[MSO_MAX_LEVELS], h[MSO_MAX_LEVELS], quota[MSO_MAX_LEVELS];
+    float sf[MSO_MAX_LEVELS];
+    mso_cvorb_geometry(W, H, p, w, h, sf, quota);
+    uint8_t* pyr[MSO_MAX_LEVELS];
+    pyr[0] = (uint8_t*)malloc((size_t)W * H);
+    mso_gray(bgr, (size_t)W * H, pyr[0]); /* orb_feature.cpp:35 */
+    for(int l = 1; l < p->n_levels; ++l)
+    {
+        pyr[l] = (uint8_t*)malloc((size_t)w[l] * h[l] + 1);
+        mso_resize_linear_exact(pyr[l - 1], w[l - 1], h[l - 1], pyr[l], w[l], h[l]);
+    }
+    const int cap = W * H / 4 + 16;
+    mso_cand* kp = (mso_cand*)malloc(sizeof(mso_cand) * (size_t)cap);
+    uint8_t* blurred = (uint8_t*)malloc((size_t)W * H);
+    int total = 0, rc = 0;
+    for(int l = 0; l < p->n_levels; ++l)
+    {
+        if(w[l] <= 2 * p->edge_threshold || h[l] <= 2 * p->edge_threshold)
+            continue;
+        const int n = mso_cvorb_level_keypoints(pyr[l], w[l], h[l], p, quota[l], 1, kp, cap);
+        if(n == 0)
+            continue;
+        mso_gaussian_blur7(pyr[l], w[l], h[l], blurred);
+        for(int i = 0; i < n; ++i)
+        {
+            const int ix = cv_round_f(kp[i].x), iy = cv_round_f(kp[i].y);
+            const float ang = mso_ic_angle(pyr[l], w[l], ix, iy); /* ICAngles: unblurred level */
+            if(total < max_out)
+            {
+                mso_cvorb_descriptor(blurred, w[l], ix, iy, ang, desc + (size_t)total * 32);
+                xy[2 * total] = kp[i].x * sf[l]; /* allKeypoints[i].pt *= scale */
+                xy[2 * total + 1] = kp[i].y * sf[l];
+                octave[total] = l;
+                angle[total] = ang;
+                response[total] = kp[i].response;
+            }
+            else
+                rc = -1;
+            ++total;
+        }
+    }
+    *n_out = total;
+    for(int l = 0; l < p->n_levels; ++l)
+        free(pyr[l]);
+    free(kp);
+    free(blurred);
+    return rc;
+}
+
+/* test hooks: the shared routine and the host libm's float cos/sin (what the reference calls) */
+void mso_sincos_f32(float x, float* s, float* c) { mslam_sincos_f32(x, s, c); }
+void mso_libm_sincosf(float x, float* s, float* c)
+{
+    *s = sinf(x);
+    *c = cosf(x);
+}

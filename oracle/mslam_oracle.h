@@ -107,6 +107,43 @@ int mso_match(const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int 
 void mso_backproject(const uint16_t* depth, int width, int height, float factor, double fx, double fy, double cx,
                      double cy, const float* xy, int n, double* xyz, uint8_t* valid);
 
+/* ---- the cv::ORB detector mode: OrbOpenCvDetector (orb_feature.cpp:25,33-65) ---------------------------------
+ * = toGrayScale + cv::ORB::create(1000)->detectAndCompute.  Everything below the call site is OpenCV 4.8.1
+ * (features2d/src/orb.cpp, imgproc resize INTER_LINEAR_EXACT, KeyPointsFilter), not in the reference tree:
+ * restated from the published algorithm, PARITY UNPINNED.
+ * Deliberate differences from the reference, both documented in DESIGN.md:
+ *  - output ORDER: retainBest() uses std::nth_element + std::partition, so the reference's order inside a level
+ *    is implementation-defined; the kept SET is well defined (response >= the n-th largest, ties kept).  The oracle
+ *    emits each level in FAST's raster order (y, then x);
+ *  - cos/sin of the keypoint angle come from include/mslam_sincos.h instead of the host libm's cosf/sinf. */
+typedef struct
+{
+    int n_features;     /* 1000  orb_feature.cpp:25            */
+    float scale_factor; /* 1.2f  cv::ORB::create default       */
+    int n_levels;       /* 8                                   */
+    int edge_threshold; /* 31                                  */
+    int fast_threshold; /* 20                                  */
+} mso_cvorb_params;
+void mso_cvorb_default_params(mso_cvorb_params* p);
+/* layerScale / layer sizes / per-level feature quota (orb.cpp getScale, detectAndCompute, computeKeyPoints) */
+void mso_cvorb_geometry(int W, int H, const mso_cvorb_params* p, int* w, int* h, float* scale, int* quota);
+/* cv::resize(..., INTER_LINEAR_EXACT) on CV_8UC1 (imgproc/src/resize.cpp resize_bitExact, ufixedpoint16) */
+void mso_resize_linear_exact(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
+/* HarrisResponses (orb.cpp), blockSize 7, k 0.04, at integer (x, y) of one level image */
+float mso_harris_response(const uint8_t* img, int step, int x, int y);
+/* computeOrbDescriptors (orb.cpp), WTA_K 2, on the blurred level */
+void mso_cvorb_descriptor(const uint8_t* blurred, int step, int x, int y, float angle_deg, uint8_t* desc);
+/* stages for the parity tests: keypoints of one level after FAST + border filter + retainBest(2n) [stage 0] or
+ * after Harris + retainBest(n) [stage 1]; raster order; response = FAST score resp. Harris response */
+int mso_cvorb_level_keypoints(const uint8_t* img, int w, int h, const mso_cvorb_params* p, int quota, int stage,
+                              mso_cand* out, int cap);
+/* whole OrbOpenCvDetector::detect; same output contract as mso_detect */
+int mso_cvorb_detect(const uint8_t* bgr, int W, int H, const mso_cvorb_params* p, int max_out, float* xy, uint8_t* desc,
+                     int32_t* octave, float* angle, float* response, int* n_out);
+
+void mso_sincos_f32(float x, float* s, float* c);   /* include/mslam_sincos.h */
+void mso_libm_sincosf(float x, float* s, float* c); /* host libm sinf / cosf */
+
 /* ---- DBoW3 (rmsalinas/DBow3 master, conan_recipes/dbow3/conanfile.py:9,18) ---------------- */
 typedef struct mso_voc mso_voc;
 enum { MSO_TF_IDF = 0, MSO_TF = 1, MSO_IDF = 2, MSO_BINARY = 3 };

@@ -222,6 +222,95 @@ def backproject(depth, xy, factor=1.0 / 5000.0, focal=(525.0, 525.0), principal=
     return xyz[:n].copy(), valid[:n].astype(bool)
 
 
+# ---- cv::ORB detector mode (OrbOpenCvDetector, orb_feature.cpp:25,33-65) -------------------------------------
+class CvOrbParams(C.Structure):
+    _fields_ = [("n_features", C.c_int), ("scale_factor", C.c_float), ("n_levels", C.c_int),
+                ("edge_threshold", C.c_int), ("fast_threshold", C.c_int)]
+
+
+def cvorb_params(n_features=1000, scale_factor=1.2, n_levels=8, edge_threshold=31, fast_threshold=20):
+    return CvOrbParams(n_features, scale_factor, n_levels, edge_threshold, fast_threshold)
+
+
+def cvorb_geometry(W, H, p):
+    w = (C.c_int * 16)()
+    h = (C.c_int * 16)()
+    s = (C.c_float * 16)()
+    q = (C.c_int * 16)()
+    lib().mso_cvorb_geometry(W, H, C.byref(p), w, h, s, q)
+    n = p.n_levels
+    return list(w[:n]), list(h[:n]), np.array(s[:n], np.float32), list(q[:n])
+
+
+def resize_linear_exact(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, sw = src.shape
+    dst = np.empty((dh, dw), np.uint8)
+    lib().mso_resize_linear_exact(_p(src), sw, sh, _p(dst), dw, dh)
+    return dst
+
+
+def cvorb_pyramid(gray0, p):
+    H, W = gray0.shape
+    w, h, _, _ = cvorb_geometry(W, H, p)
+    pyr = [np.ascontiguousarray(gray0)]
+    for l in range(1, p.n_levels):
+        pyr.append(resize_linear_exact(pyr[-1], w[l], h[l]))
+    return pyr
+
+
+def harris_response(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    lib().mso_harris_response.restype = C.c_float
+    return lib().mso_harris_response(_p(img), img.shape[1], int(x), int(y))
+
+
+def cvorb_level_keypoints(img, p, quota, stage):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h // 4 + 16
+    out = np.zeros(cap, CAND_DT)
+    n = lib().mso_cvorb_level_keypoints(_p(img), w, h, C.byref(p), int(quota), int(stage), _p(out), cap)
+    return out[:n].copy()
+
+
+def cvorb_detect(bgr, p, max_out=100000):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    H, W = bgr.shape[:2]
+    xy = np.empty((max_out, 2), np.float32)
+    desc = np.empty((max_out, 32), np.uint8)
+    octave = np.empty(max_out, np.int32)
+    angle = np.empty(max_out, np.float32)
+    resp = np.empty(max_out, np.float32)
+    n = C.c_int(0)
+    rc = lib().mso_cvorb_detect(_p(bgr), W, H, C.byref(p), max_out, _p(xy), _p(desc), _p(octave), _p(angle), _p(resp),
+                                C.byref(n))
+    if rc != 0:
+        raise RuntimeError("oracle cvorb_detect: capacity %d exceeded (%d keypoints)" % (max_out, n.value))
+    k = n.value
+    return dict(xy=xy[:k].copy(), desc=desc[:k].copy(), octave=octave[:k].copy(), angle=angle[:k].copy(),
+                response=resp[:k].copy())
+
+
+def cvorb_descriptor(blurred, x, y, angle_deg):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    d = np.empty(32, np.uint8)
+    lib().mso_cvorb_descriptor(_p(blurred), blurred.shape[1], int(x), int(y), C.c_float(angle_deg), _p(d))
+    return d
+
+
+def sincos_f32(x):
+    s, c = C.c_float(), C.c_float()
+    lib().mso_sincos_f32(C.c_float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def libm_sincosf(x):
+    s, c = C.c_float(), C.c_float()
+    lib().mso_libm_sincosf(C.c_float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
 class Vocabulary:
     def __init__(self, blob):
         self._blob = np.frombuffer(bytes(blob), np.uint8) if not isinstance(blob, np.ndarray) else blob

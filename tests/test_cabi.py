@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.lib()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.mslam_hip_abi_version() == 1
+    assert lib.mslam_hip_abi_version() == 2   # 2: mslam_hip_params gained detector / n_features / edge_threshold
 
 
 def test_default_params_are_the_reference_operating_point(pkg):
@@ -31,11 +31,14 @@ def test_default_params_are_the_reference_operating_point(pkg):
     # distributed_cv_feature.cpp:1184-1186
     assert (p.n_levels, p.ini_fast_thr, p.min_fast_thr, p.min_node_area) == (8, 20, 7, 1000)
     assert abs(p.scale_factor - 1.2) < 1e-7 and (p.width, p.height) == (640, 480)
+    # the in-tree detector by default; the cv::ORB mode's own defaults are orb_feature.cpp:25 / cv::ORB::create
+    assert (p.detector, p.n_features, p.edge_threshold) == (pkg.DETECTOR_DISTRIBUTED, 1000, 31)
 
 
 def test_invalid_parameters_are_rejected(pkg):
     for kw in (dict(width=0), dict(n_levels=17), dict(scale_factor=1.0), dict(min_fast_thr=30), dict(max_batch=0),
-               dict(width=60, height=50), dict(width=5000, height=480)):
+               dict(width=60, height=50), dict(width=5000, height=480), dict(detector=7),
+               dict(detector=1, edge_threshold=5), dict(detector=1, width=20, height=20)):
         with pytest.raises(pkg.MslamHipError) as e:
             pkg.Context(**kw)
         assert e.value.code == pkg.E_INVALID, kw

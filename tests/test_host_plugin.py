@@ -28,7 +28,8 @@ def built():
 
 def test_plugin_exports_boost_style_aliases(built):
     out = subprocess.check_output(["nm", "-D", PLUGIN]).decode()
-    for alias in ("hipOrbDetectorFactory", "hipOrbMatcherFactory", "hipOrbRelocalizerFactory", "loopDetection"):
+    for alias in ("hipOrbDetectorFactory", "hipCvOrbDetectorFactory", "hipOrbMatcherFactory", "hipOrbRelocalizerFactory",
+                  "loopDetection"):
         assert any(line.split()[-1] == alias and line.split()[-2] in "DdBb" for line in out.splitlines()), alias
     sec = subprocess.check_output(["readelf", "-S", PLUGIN]).decode()
     assert "boostdll" in sec  # the section BOOST_DLL_ALIAS uses
@@ -111,3 +112,30 @@ def test_plugin_bow_boundary(built, orc, synth_frames, tmp_path):
     for t in range(n):
         assert "relocalize %d: %s" % (t, " ".join(str(100 + e) for e in ranked(t, range(n))[:4])) in lines
     assert "after remove 0: %s" % " ".join(str(100 + e) for e in ranked(0, range(1, n))[:4]) in lines
+
+
+@pytest.mark.gpu
+def test_plugin_cv_orb_detector(built, orc, bundled_frames, tmp_path):
+    """hipCvOrbDetectorFactory: the OrbOpenCvDetector drop-in (orb_feature.cpp:25,33-65) through the loader"""
+    paths = []
+    for i, f in enumerate(bundled_frames):
+        p = tmp_path / ("f%d.bgr" % i)
+        p.write_bytes(f.tobytes())
+        paths.append(str(p))
+    env = dict(os.environ, MSLAM_HARNESS_DETECTOR="cvorb")
+    r = subprocess.run([HARNESS, PLUGIN, "640", "480"] + paths, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    dets = [orc.cvorb_detect(f, orc.cvorb_params()) for f in bundled_frames]
+    for i, d in enumerate(dets):
+        h = 0x811C9DC5
+        for k in range(len(d["xy"])):
+            h = _fnv(struct.pack("<Q", k), h)
+            h = _fnv(struct.pack("<dd", float(d["xy"][k, 0]), float(d["xy"][k, 1])), h)
+            h = _fnv(d["desc"][k].tobytes(), h)
+        assert "frame %d keypoints %d fnv %08x" % (i, len(d["xy"]), h) in lines
+    fi, ti = orc.match(dets[1]["desc"], dets[0]["desc"])
+    h = 0x811C9DC5
+    for a, b in zip(fi, ti):
+        h = _fnv(struct.pack("<QQ", int(a), int(b)), h)
+    assert "match 1 pairs %d fnv %08x" % (len(fi), h) in lines
