@@ -169,6 +169,18 @@ enum
 int mslam_hip_bow_load(mslam_hip_ctx* ctx, const void* blob, size_t size);
 int mslam_hip_bow_info(mslam_hip_ctx* ctx, int* k, int* L, int* n_nodes, int* n_words, int* scoring,
                        int* weighting);
+/* How a descriptor is assigned to a word, for every entry point below:
+ * TREE = Vocabulary::transform's descent (dbow3.patch:1760-1860: at each level the child with the least Hamming
+ * distance, first child on ties) — what DBoW3 does, the default;
+ * FLAT = the exhaustive descriptor-vs-vocabulary search the descent approximates (BASELINE.json north_star's
+ * "batched descriptor-vs-vocabulary Hamming kernel", SURVEY.md §8d bow_flat): the leaf with the least distance
+ * over ALL words, lower word id on ties.  n x n_words distance evaluations: a stress mode, not a DBoW3 drop-in. */
+enum
+{
+    MSLAM_BOW_ASSIGN_TREE = 0,
+    MSLAM_BOW_ASSIGN_FLAT = 1
+};
+int mslam_hip_bow_set_assignment(mslam_hip_ctx* ctx, int mode);
 /* Vocabulary::transform(feature, word_id, weight) for n descriptors (dbow3.patch:1760-1860). */
 int mslam_hip_bow_words(mslam_hip_ctx* ctx, const uint8_t* desc, int n, uint32_t* word, double* weight);
 /* Vocabulary::transform(features, BowVector) (dbow3.patch:1432-1530): ascending word ids, values

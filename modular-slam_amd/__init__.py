@@ -27,6 +27,7 @@ OK, E_INVALID, E_RUNTIME, E_CAPACITY, E_NO_VOCABULARY, E_FORMAT = range(6)
 DBG_PYRAMID, DBG_BLURRED, DBG_CANDIDATES, DBG_SELECTED = range(4)
 MATCHER_AUTO, MATCHER_POPCOUNT = 0, 1
 DETECTOR_DISTRIBUTED, DETECTOR_CV_ORB = 0, 1
+BOW_ASSIGN_TREE, BOW_ASSIGN_FLAT = 0, 1
 
 # every symbol include/mslam_hip.h declares (tests/test_cabi.py checks the .so exports them all)
 ABI_SYMBOLS = [
@@ -39,7 +40,7 @@ ABI_SYMBOLS = [
     "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host", "mslam_hip_backproject", "mslam_hip_backproject_batch_dev",
     "mslam_hip_get_points_view", "mslam_hip_set_matcher", "mslam_hip_get_matcher",
     "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
-    "mslam_hip_join_matcher", "mslam_hip_bow_db_remove",
+    "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
 ]
 
 
@@ -238,6 +239,10 @@ class Context:
         v = [C.c_int() for _ in range(6)]
         self._chk(self.L.mslam_hip_bow_info(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("k", "L", "n_nodes", "n_words", "scoring", "weighting"), [x.value for x in v]))
+
+    def bow_set_assignment(self, mode):
+        """BOW_ASSIGN_TREE (DBoW3's descent) or BOW_ASSIGN_FLAT (exhaustive search over all words)"""
+        self._chk(self.L.mslam_hip_bow_set_assignment(self._h, int(mode)))
 
     def bow_words(self, desc):
         d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)

@@ -57,6 +57,11 @@ struct BowState
     int32_t* d_best_entry = nullptr; // [B+1]
     double* d_best_score = nullptr;
     uint8_t* d_hdesc = nullptr;     // host-pointer query descriptors [cap][32]
+    // flat mode (SURVEY.md §8d bow_flat): the leaves' descriptors / weights in word-id order, per-feature best keys
+    uint32_t* d_leaf_desc = nullptr; // [n_words][8]
+    double* d_leaf_weight = nullptr; // [n_words]
+    uint32_t* d_fbest = nullptr;     // [B+1][cap] (distance << 20) | word
+    int flat = 0;                    // MSLAM_BOW_ASSIGN_*
     int cap = 0, B = 0;
 };
 
@@ -64,7 +69,8 @@ static void bow_free(BowState* b)
 {
     void* bufs[] = {b->d_desc,   b->d_first,   b->d_nchild, b->d_word,   b->d_weight,     b->d_fword,      b->d_fweight,
                     b->d_bwords, b->d_bvalues, b->d_bn,     b->d_rwords, b->d_rvalues,    b->d_rn,         b->d_scores,
-                    b->d_best_entry, b->d_best_score, b->d_hdesc, b->d_contrib, b->d_match_cnt};
+                    b->d_best_entry, b->d_best_score, b->d_hdesc, b->d_contrib, b->d_match_cnt,
+                    b->d_leaf_desc,  b->d_leaf_weight, b->d_fbest};
     for(void* p : bufs)
         if(p)
             (void)hipFree(p);
@@ -139,6 +145,85 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t* __restrict__
         out_word[o] = word[node];
         out_weight[o] = weight[node];
     }
+}
+
+// ---- flat word assignment (north_star: "a batched descriptor-vs-vocabulary Hamming kernel"; SURVEY.md §8d bow_flat) ----
+// word(d) = argmin over ALL leaves of the 256-bit Hamming distance, ties to the lower word id — the exhaustive
+// search the tree descent approximates.  Same structure as the xor/popcount matcher (k_match.hip): one lane owns one
+// descriptor, a leaf row is wave-uniform and arrives through the scalar unit (s_load_dwordx8), 8 xor + 8 v_bcnt per
+// pair; the running minimum is a packed key (distance << 20 | word), unique per word.  The vocabulary is cut into
+// slices (gridDim.y) so that 10^6 leaves fill the chip even for one frame; slices merge with atomicMin on the key,
+// which is order-independent.  Not HBM-bound: n x V distance evaluations against (n + V) x 32 bytes.
+constexpr int kFlatWaves = 4;
+
+__device__ __forceinline__ uint32_t bow_bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+
+__global__ __launch_bounds__(64 * kFlatWaves) void k_bow_flat(const uint8_t* __restrict__ desc, long long desc_stride,
+                                                               const int32_t* __restrict__ counts, int n_fixed, int cap,
+                                                               const uint32_t* __restrict__ leaves, int n_words,
+                                                               int slice, uint32_t* __restrict__ best)
+{
+    const int frame = blockIdx.z;
+    const int n = min(counts ? counts[frame] : n_fixed, cap);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * 64 + lane;
+    if(blockIdx.x * 64 >= n)
+        return;
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if(q < n)
+    {
+        const uint4* qp = reinterpret_cast<const uint4*>(desc + (long long)frame * desc_stride + (size_t)q * 32);
+        qa = qp[0];
+        qb = qp[1];
+    }
+    const int s0 = blockIdx.y * slice, s1 = min(n_words, s0 + slice);
+    const int chunk = (s1 - s0 + kFlatWaves - 1) / kFlatWaves;
+    const int j0 = s0 + wave * chunk, j1 = min(s1, j0 + chunk);
+    uint32_t b0 = 0xFFFFFFFFu;
+    auto row = [&](int j) {
+        const uint32_t* __restrict__ t = leaves + (size_t)j * 8; // wave-uniform address -> s_load_dwordx8
+        uint32_t d = __popc(qa.x ^ t[0]);
+        d = bow_bcnt_acc(qa.y ^ t[1], d);
+        d = bow_bcnt_acc(qa.z ^ t[2], d);
+        d = bow_bcnt_acc(qa.w ^ t[3], d);
+        d = bow_bcnt_acc(qb.x ^ t[4], d);
+        d = bow_bcnt_acc(qb.y ^ t[5], d);
+        d = bow_bcnt_acc(qb.z ^ t[6], d);
+        d = bow_bcnt_acc(qb.w ^ t[7], d);
+        b0 = min(b0, (d << 20) | (uint32_t)j);
+    };
+    int j = j0;
+    for(; j + 8 <= j1; j += 8)
+    {
+#pragma unroll
+        for(int k = 0; k < 8; ++k)
+            row(j + k);
+    }
+    for(; j < j1; ++j)
+        row(j);
+    if(q < n && b0 != 0xFFFFFFFFu)
+        atomicMin(&best[(size_t)frame * cap + q], b0);
+}
+
+__global__ __launch_bounds__(256) void k_bow_flat_finish(const uint32_t* __restrict__ best, const int32_t* __restrict__ counts,
+                                                         int n_fixed, int cap, const double* __restrict__ leaf_weight,
+                                                         uint32_t* __restrict__ out_word, double* __restrict__ out_weight)
+{
+    const int frame = blockIdx.y;
+    const int n = min(counts ? counts[frame] : n_fixed, cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= n)
+        return;
+    const size_t o = (size_t)frame * cap + i;
+    const uint32_t w = best[o] & 0xFFFFFu;
+    out_word[o] = w;
+    out_weight[o] = leaf_weight[w];
 }
 
 constexpr int VT = 512;
@@ -800,6 +885,9 @@ static int bow_load_impl(mslam_hip_ctx* c, const void* blob, size_t size)
     BALLOC(b->d_best_entry, B + 1);
     BALLOC(b->d_best_score, B + 1);
     BALLOC(b->d_hdesc, cap * 32);
+    BALLOC(b->d_leaf_desc, (size_t)n_words * 8);
+    BALLOC(b->d_leaf_weight, n_words);
+    BALLOC(b->d_fbest, (B + 1) * cap);
 #undef BALLOC
     bool ok = hipMemcpy(b->d_desc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(b->d_first, sfirst.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -807,6 +895,29 @@ static int bow_load_impl(mslam_hip_ctx* c, const void* blob, size_t size)
               hipMemcpy(b->d_word, sword.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(b->d_weight, sweight.data(), n_nodes * 8, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemset(b->d_rn, 0, RP * 4) == hipSuccess && hipMemset(b->d_bn, 0, (B + 1) * 4) == hipSuccess;
+    {
+        // leaves in word-id order for the flat search (a word id is 20 bits in its key)
+        std::vector<uint8_t> ldesc((size_t)n_words * 32, 0);
+        std::vector<double> lweight(n_words, 0.0);
+        std::vector<uint8_t> seen(n_words, 0);
+        bool leaves_ok = n_words <= (1u << 20);
+        for(uint32_t nid = 0; nid < n_nodes && leaves_ok; ++nid)
+            if(nid != 0 && nchild[nid] == 0)
+            {
+                const uint32_t w = word[nid];
+                if(w >= n_words || seen[w])
+                    leaves_ok = false;
+                else
+                {
+                    seen[w] = 1;
+                    std::memcpy(&ldesc[(size_t)w * 32], &desc[(size_t)nid * 32], 32);
+                    lweight[w] = weight[nid];
+                }
+            }
+        b->flat = leaves_ok ? 0 : -1; // -1: flat mode unavailable for this vocabulary (words are not 1:1 with leaves)
+        ok = ok && hipMemcpy(b->d_leaf_desc, ldesc.data(), ldesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(b->d_leaf_weight, lweight.data(), lweight.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    }
     if(!ok)
     {
         c->err = "bow_load: upload failed";
@@ -825,6 +936,22 @@ static int bow_transform_dev(mslam_hip_ctx* c, const uint8_t* d_desc, long long 
     BowState* b = c->bow;
     hipStream_t s = c->stream;
     const int cap = b->cap;
+    if(b->flat == 1)
+    {
+        StageScope t(c, "bow_flat");
+        uint32_t* best = b->d_fbest + (size_t)slot0 * cap;
+        BHIPCHK(c, hipMemsetAsync(best, 0xFF, (size_t)n_frames * cap * 4, s));
+        // slices: enough workgroups to fill 256 CUs x 8 even for a single frame, at least 2048 words each
+        const int qblocks = (cap + 63) / 64;
+        int n_slices = std::max(1, std::min((int)((b->n_words + 2047) / 2048), std::max(1, 4096 / std::max(1, qblocks * n_frames))));
+        const int slice = (int)((b->n_words + n_slices - 1) / n_slices);
+        n_slices = (int)((b->n_words + slice - 1) / slice);
+        hipLaunchKernelGGL(k_bow_flat, dim3(qblocks, n_slices, n_frames), dim3(64 * kFlatWaves), 0, s, d_desc, stride, d_counts,
+                           n_fixed, cap, b->d_leaf_desc, (int)b->n_words, slice, best);
+        hipLaunchKernelGGL(k_bow_flat_finish, dim3((cap + 255) / 256, n_frames), dim3(256), 0, s, best, d_counts, n_fixed, cap,
+                           b->d_leaf_weight, b->d_fword + (size_t)slot0 * cap, b->d_fweight + (size_t)slot0 * cap);
+    }
+    else
     {
         StageScope t(c, "bow_descend");
         const int groups_per_block = 256 / kBowGroup;
@@ -1083,6 +1210,19 @@ int mslam_hip_bow_db_query(mslam_hip_ctx* c, const uint8_t* desc, int n, int max
         scores[i] = res[i].first;
     }
     *n_results = m;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_set_assignment(mslam_hip_ctx* c, int mode)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    if(mode != MSLAM_BOW_ASSIGN_TREE && mode != MSLAM_BOW_ASSIGN_FLAT)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_set_assignment: unknown mode");
+    if(mode == MSLAM_BOW_ASSIGN_FLAT && c->bow->flat < 0)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_set_assignment: this vocabulary's words are not one per leaf (or more than 2^20)");
+    c->bow->flat = mode;
     return MSLAM_HIP_OK;
 }
 

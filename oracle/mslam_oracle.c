@@ -1417,3 +1417,22 @@ void mso_libm_sincosf(float x, float* s, float* c)
     *s = sinf(x);
     *c = cosf(x);
 }
+
+/* flat word assignment (SURVEY.md §8d bow_flat; not a DBoW3 function): the word whose leaf descriptor has the least
+ * Hamming distance over ALL words, lower word id on ties — the exhaustive search the descent approximates */
+void mso_bow_words_flat(const mso_voc* v, const uint8_t* desc, int n, uint32_t* word, double* weight)
+{
+    for(int r = 0; r < n; ++r)
+    {
+        int best_d = 1 << 30;
+        uint32_t best_w = 0;
+        for(uint32_t w = 0; w < v->n_words; ++w)
+        {
+            const int d = hamming256(desc + (size_t)r * 32, v->desc + (size_t)v->words[w] * 32);
+            if(d < best_d)
+                best_d = d, best_w = w;
+        }
+        word[r] = best_w;
+        weight[r] = v->weight[v->words[best_w]];
+    }
+}

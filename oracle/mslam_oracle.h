@@ -155,6 +155,8 @@ void mso_voc_free(mso_voc* v);
 int mso_voc_info(const mso_voc* v, int* k, int* L, int* n_nodes, int* n_words, int* scoring, int* weighting);
 /* Vocabulary::transform(feature, word_id, weight), dbow3.patch:1760-1860 */
 void mso_bow_words(const mso_voc* v, const uint8_t* desc, int n, uint32_t* word, double* weight);
+/* exhaustive assignment over all words (SURVEY.md §8d bow_flat), lower word id on ties */
+void mso_bow_words_flat(const mso_voc* v, const uint8_t* desc, int n, uint32_t* word, double* weight);
 /* Vocabulary::transform(features, BowVector), dbow3.patch:1432-1530; ascending word order. */
 int mso_bow_vector(const mso_voc* v, const uint8_t* desc, int n, uint32_t* words, double* values);
 /* DBoW3 L1Scoring::score (published algorithm; not in the reference tree) */

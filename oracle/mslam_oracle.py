@@ -333,6 +333,13 @@ class Vocabulary:
         lib().mso_bow_words(C.c_void_p(self._h), _p(d), len(d), _p(w), _p(wt))
         return w, wt
 
+    def words_flat(self, desc):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        w = np.empty(len(d), np.uint32)
+        wt = np.empty(len(d), np.float64)
+        lib().mso_bow_words_flat(C.c_void_p(self._h), _p(d), len(d), _p(w), _p(wt))
+        return w, wt
+
     def bow_vector(self, desc):
         d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
         w = np.empty(max(len(d), 1), np.uint32)

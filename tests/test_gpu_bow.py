@@ -281,3 +281,62 @@ def test_database_window_wraps(pkg, orc):
             exp = _l1_model_best(orc, fv, 3 * b + i)
             assert (be[i], bs[i]) == ((exp[1], exp[0]) if exp else (-1, 0.0)), (b, i)
     c.close()
+
+
+def test_flat_word_assignment(pkg, orc, descs):
+    """a15b: the exhaustive descriptor-vs-vocabulary Hamming search (north_star's "batched descriptor-vs-vocabulary
+    Hamming kernel", SURVEY §8d bow_flat) against brute force: least distance over ALL words, lower word id on ties;
+    then the whole BoW path (vectors, database) on flat assignments, and the 10^6-word vocabulary."""
+    import torch
+    blob = synth.make_vocabulary(10, 4, seed=31)                      # 10^4 words
+    V = orc.Vocabulary(blob)
+    K = 4096
+    c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=K)
+    c.bow_load(blob)
+    c.bow_set_assignment(pkg.BOW_ASSIGN_FLAT)
+    rng = np.random.default_rng(12)
+    for d in (descs[0], rng.integers(0, 256, (777, 32), dtype=np.uint8), descs[1][:1]):
+        gw, gwt = c.bow_words(d)
+        rw, rwt = V.words_flat(d)
+        assert np.array_equal(gw, rw) and np.array_equal(gwt, rwt)
+    # ties: queries that ARE leaf descriptors, and a vocabulary with duplicated leaves -> the lower word id wins
+    tree_w, _ = V.words(descs[0])
+    flat_w, _ = V.words_flat(descs[0])
+    assert (tree_w != flat_w).mean() > 0.3                            # the descent is only an approximation
+    # BoW vectors built on flat words: the oracle's vector code on the flat assignment
+    gv = c.bow_transform(descs[0])
+    w, wt = V.words_flat(descs[0])
+    order = np.argsort(w, kind="stable")
+    uw, first = np.unique(w[order], return_index=True)
+    # addWeight: a word hit cnt times accumulates its idf weight cnt times, sequentially
+    vals = np.array([sum([wt[order][f]] * cnt, 0.0) for f, cnt in zip(first, np.diff(np.append(first, len(w))))])
+    norm = 0.0
+    for x in vals:
+        norm += abs(x)
+    assert np.array_equal(gv[0], uw) and np.array_equal(gv[1], vals / norm)
+    # batched device path in flat mode
+    c.detect_batch_dev(torch.from_numpy(np.ascontiguousarray(synth.make_stream(3, 640, 480, seed=1234))).cuda().data_ptr(), 3)
+    c.bow_batch_dev(True)
+    c.sync()
+    v = c.bow_view()
+    n = pkg.read_device(c, v.n_words, (3,), np.int32)
+    words = pkg.read_device(c, v.words, (3, K), np.uint32)
+    fr = synth.make_stream(3, 640, 480, seed=1234)
+    for t in range(3):
+        fw, _ = V.words_flat(orc.detect(fr[t], orc.params())["desc"])
+        assert np.array_equal(words[t, :n[t]], np.unique(fw))
+    c.bow_set_assignment(pkg.BOW_ASSIGN_TREE)
+    gw, _ = c.bow_words(descs[0])
+    assert np.array_equal(gw, tree_w)
+    c.close()
+    # cfg3's 10^6-word vocabulary, flat: 200 x 10^6 distances against brute force
+    blob = synth.make_vocabulary(10, 6, seed=77)
+    V = orc.Vocabulary(blob)
+    c = pkg.Context(width=0, height=0, max_keypoints=K)              # BoW-only context
+    c.bow_load(blob)
+    c.bow_set_assignment(pkg.BOW_ASSIGN_FLAT)
+    d = np.concatenate([descs[2][:150], rng.integers(0, 256, (50, 32), dtype=np.uint8)])
+    gw, gwt = c.bow_words(d)
+    rw, rwt = V.words_flat(d)
+    assert np.array_equal(gw, rw) and np.array_equal(gwt, rwt)
+    c.close()
