@@ -165,7 +165,11 @@ enum
     MSLAM_BOW_DOT_PRODUCT = 5
 };
 /* Only L1_NORM scoring vocabularies are accepted (the ORB vocabularies DBoW3 ships are TF_IDF / L1_NORM).
- * The database keeps the 64 most recent entries (a ring); older entries are dropped. */
+ * The database (DBoW3::Database(voc, false, 0), orb_relocalizer.cpp:29) is an inverted file on the device: word ->
+ * rows of (entry, value).  It is unbounded: storage grows by doubling (mslam_hip_bow_db_reserve pre-allocates);
+ * mslam_hip_bow_db_query scores against EVERY entry ever added and not removed.  The batched device form
+ * (mslam_hip_bow_batch_dev) scores every frame against the 64 entries that precede it and
+ * adds its vectors to the same database. */
 int mslam_hip_bow_load(mslam_hip_ctx* ctx, const void* blob, size_t size);
 int mslam_hip_bow_info(mslam_hip_ctx* ctx, int* k, int* L, int* n_nodes, int* n_words, int* scoring,
                        int* weighting);
@@ -199,6 +203,8 @@ int mslam_hip_bow_db_query(mslam_hip_ctx* ctx, const uint8_t* desc, int n, int m
 /* IRelocalizer::removeKeyframe: the entry is never reported again (its id is not reused). */
 int mslam_hip_bow_db_remove(mslam_hip_ctx* ctx, int entry_id);
 int mslam_hip_bow_db_clear(mslam_hip_ctx* ctx);
+int mslam_hip_bow_db_reserve(mslam_hip_ctx* ctx, int max_entries);
+int mslam_hip_bow_db_size(mslam_hip_ctx* ctx, int* n_entries);
 /* Batched device form: transform every frame of the last detect batch into a BoW vector, score it
  * against the database (all entries), then add it as a new entry.  Per frame: best entry and score. */
 int mslam_hip_bow_batch_dev(mslam_hip_ctx* ctx, int add_to_db);

@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "mslam_hip_get_points_view", "mslam_hip_set_matcher", "mslam_hip_get_matcher",
     "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
+    "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size",
 ]
 
 
@@ -284,6 +285,14 @@ class Context:
 
     def bow_db_remove(self, entry_id):
         self._chk(self.L.mslam_hip_bow_db_remove(self._h, int(entry_id)))
+
+    def bow_db_reserve(self, max_entries):
+        self._chk(self.L.mslam_hip_bow_db_reserve(self._h, int(max_entries)))
+
+    def bow_db_size(self):
+        n = C.c_int(0)
+        self._chk(self.L.mslam_hip_bow_db_size(self._h, C.byref(n)))
+        return n.value
 
     def bow_db_clear(self):
         self._chk(self.L.mslam_hip_bow_db_clear(self._h))

@@ -696,6 +696,8 @@ static int check_flags(mslam_hip_ctx* c)
         m += " keypoints in a frame > max_keypoints;";
     if(f & kFlagQuadNoConverge)
         m += " quadtree pass limit;";
+    if(f & kFlagDbFull)
+        m += " the BoW database is full (mslam_hip_bow_db_reserve);";
     if(f & kFlagBowPackOverflow)
         m += " a BoW vector has more words than the exchange format's k_max;";
     return fail(c, MSLAM_HIP_E_CAPACITY, m);

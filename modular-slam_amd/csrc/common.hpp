@@ -63,7 +63,8 @@ enum : uint32_t
     kFlagCandOverflow = 1u,  // more FAST candidates on a level than max_candidates
     kFlagKpOverflow = 2u,    // more keypoints in a frame than max_keypoints
     kFlagQuadNoConverge = 4u, // quadtree pass limit hit (cannot happen for sane sizes)
-    kFlagBowPackOverflow = 8u // a BoW vector has more words than the exchange format's k_max
+    kFlagBowPackOverflow = 8u, // a BoW vector has more words than the exchange format's k_max
+    kFlagDbFull = 16u          // the BoW database's posting log is full (mslam_hip_bow_db_reserve)
 };
 
 // ---- kernel launchers (each enqueues on `s`, no synchronisation) ----------------------------------

@@ -62,6 +62,25 @@ struct BowState
     double* d_leaf_weight = nullptr; // [n_words]
     uint32_t* d_fbest = nullptr;     // [B+1][cap] (distance << 20) | word
     int flat = 0;                    // MSLAM_BOW_ASSIGN_*
+    // inverted file of the database (DBoW3 Database: m_ifile, word -> (entry, value) rows).  Postings live in an
+    // append-only log, entry after entry; the rows of a word are a linked list threaded through the log
+    // (ix_prev), newest first, anchored at ix_head[word].  Index 0 is the null posting.
+    uint32_t* ix_head = nullptr;     // [n_words]
+    uint32_t* ix_entry = nullptr;    // [ix_cap_postings + 1]
+    uint32_t* ix_prev = nullptr;
+    double* ix_value = nullptr;
+    uint32_t* ix_size = nullptr;     // device counter: postings used
+    uint8_t* ix_removed = nullptr;   // [ix_max_entries]
+    // query scratch
+    uint32_t* ix_cnt = nullptr;      // [ix_max_entries] common words per entry
+    uint32_t* ix_ofs = nullptr;      // [ix_max_entries + 1]
+    uint32_t* ix_fill = nullptr;     // [ix_max_entries]
+    uint32_t* ix_keys = nullptr;     // [ix_cap_terms] rank of the query word
+    double* ix_vals = nullptr;       // [ix_cap_terms] the L1 term
+    double* ix_scores = nullptr;     // [ix_max_entries]
+    uint32_t* ix_total = nullptr;    // device: number of terms of the last query (for the capacity check)
+    long long ix_max_entries = 0;
+    size_t ix_cap_postings = 0, ix_cap_terms = 0;
     int cap = 0, B = 0;
 };
 
@@ -70,7 +89,9 @@ static void bow_free(BowState* b)
     void* bufs[] = {b->d_desc,   b->d_first,   b->d_nchild, b->d_word,   b->d_weight,     b->d_fword,      b->d_fweight,
                     b->d_bwords, b->d_bvalues, b->d_bn,     b->d_rwords, b->d_rvalues,    b->d_rn,         b->d_scores,
                     b->d_best_entry, b->d_best_score, b->d_hdesc, b->d_contrib, b->d_match_cnt,
-                    b->d_leaf_desc,  b->d_leaf_weight, b->d_fbest};
+                    b->d_leaf_desc,  b->d_leaf_weight, b->d_fbest, b->ix_head, b->ix_entry, b->ix_prev, b->ix_value,
+                    b->ix_size, b->ix_removed, b->ix_cnt, b->ix_ofs, b->ix_fill, b->ix_keys, b->ix_vals, b->ix_scores,
+                    b->ix_total};
     for(void* p : bufs)
         if(p)
             (void)hipFree(p);
@@ -599,6 +620,160 @@ __global__ __launch_bounds__(64) void k_bow_cross_score(const uint32_t* __restri
     scores[(size_t)t * n_sets + r] = -s / 2.0;
 }
 
+// ---- inverted file (DBoW3 Database::add / queryL1; sources not in the reference tree, published algorithm) -------------
+// add: every (word, value) of the new entries is appended to the log and pushed on its word's list.  Several entries
+// added by one launch may share words: atomicExch keeps every list intact whatever the order.
+__global__ void k_ix_alloc(const int32_t* __restrict__ bn, int n_entries, uint32_t* __restrict__ size,
+                           uint32_t* __restrict__ starts /*[n_entries]*/, uint32_t cap_postings, uint32_t* __restrict__ flags)
+{
+    uint32_t s = *size;
+    for(int t = 0; t < n_entries; ++t)
+    {
+        starts[t] = s;
+        s += (uint32_t)bn[t];
+    }
+    if(s > cap_postings)
+        atomicOr(flags, kFlagDbFull); // nothing is appended by k_ix_append in that case
+    else
+        *size = s;
+}
+
+__global__ __launch_bounds__(256) void k_ix_append(const uint32_t* __restrict__ bwords, const double* __restrict__ bvalues,
+                                                   const int32_t* __restrict__ bn, int cap, long long base_id,
+                                                   const uint32_t* __restrict__ starts, const uint32_t* __restrict__ size,
+                                                   uint32_t cap_postings, uint32_t* __restrict__ head,
+                                                   uint32_t* __restrict__ ix_entry, uint32_t* __restrict__ ix_prev,
+                                                   double* __restrict__ ix_value)
+{
+    const int t = blockIdx.x;
+    const int n = bn[t];
+    const uint32_t start = starts[t];
+    if((size_t)start + n > cap_postings || start + (uint32_t)n > *size)
+        return; // the log is full (flagged by k_ix_alloc)
+    for(int i = threadIdx.x; i < n; i += 256)
+    {
+        const uint32_t idx = start + i + 1; // 0 = null
+        const uint32_t w = bwords[(size_t)t * cap + i];
+        ix_entry[idx] = (uint32_t)(base_id + t);
+        ix_value[idx] = bvalues[(size_t)t * cap + i];
+        ix_prev[idx] = atomicExch(&head[w], idx);
+    }
+}
+
+// query, pass 1 and 2: one thread per query word (rank i in ascending word order) walks that word's list.
+// FILL = false: count the common words of every entry; FILL = true: store (rank, term) into the entry's segment.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ix_walk(const uint32_t* __restrict__ qwords, const double* __restrict__ qvalues,
+                                                 const int32_t* __restrict__ qn, const uint32_t* __restrict__ head,
+                                                 const uint32_t* __restrict__ ix_entry, const uint32_t* __restrict__ ix_prev,
+                                                 const double* __restrict__ ix_value, const uint8_t* __restrict__ removed,
+                                                 long long id_limit, uint32_t* __restrict__ cnt,
+                                                 const uint32_t* __restrict__ ofs, uint32_t* __restrict__ fill,
+                                                 uint32_t* __restrict__ keys, double* __restrict__ vals, uint32_t cap_terms)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= *qn)
+        return;
+    const double vi = qvalues[i];
+    uint32_t idx = head[qwords[i]];
+    while(idx != 0)
+    {
+        const uint32_t e = ix_entry[idx];
+        if((long long)e < id_limit && !removed[e])
+        {
+            if(!FILL)
+                atomicAdd(&cnt[e], 1u);
+            else
+            {
+                const uint32_t p = ofs[e] + atomicAdd(&fill[e], 1u);
+                if(p < cap_terms)
+                {
+                    const double wi = ix_value[idx];
+                    keys[p] = (uint32_t)i;
+                    vals[p] = fabs(vi - wi) - fabs(vi) - fabs(wi); // L1Scoring::score term
+                }
+            }
+        }
+        idx = ix_prev[idx];
+    }
+}
+
+// exclusive scan of the per-entry counts (one workgroup; N is the number of entries ever added)
+__global__ __launch_bounds__(1024) void k_ix_scan(const uint32_t* __restrict__ cnt, long long n, uint32_t* __restrict__ ofs,
+                                                  uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const long long per = (n + 1023) / 1024, b = tid * per, e = min(n, b + per);
+    uint32_t s = 0;
+    for(long long k = b; k < e; ++k)
+        s += cnt[k];
+    part[tid] = s;
+    __syncthreads();
+    for(int o = 1; o < 1024; o <<= 1)
+    {
+        const uint32_t t = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for(long long k = b; k < e; ++k)
+    {
+        ofs[k] = run;
+        run += cnt[k];
+    }
+    if(tid == 1023)
+    {
+        ofs[n] = part[1023];
+        *total = part[1023];
+    }
+}
+
+// pass 3: one wave per entry.  The terms of an entry were stored in arrival order; the reference adds them in
+// ascending word order (std::map iteration in Database::queryL1), i.e. ascending rank: pick the smallest rank
+// above the last one, add its term, repeat.  Ranks are unique inside an entry.
+__global__ __launch_bounds__(256) void k_ix_sum(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ofs,
+                                                const uint32_t* __restrict__ keys, const double* __restrict__ vals,
+                                                long long n, double* __restrict__ scores)
+{
+    const int lane = threadIdx.x & 63;
+    for(long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += (long long)gridDim.x * 4)
+    {
+        const uint32_t c = cnt[e];
+        if(c == 0)
+        {
+            if(lane == 0)
+                scores[e] = -1.0; // no common word: Database::queryL1 does not report the entry
+            continue;
+        }
+        const uint32_t* k = keys + ofs[e];
+        const double* v = vals + ofs[e];
+        double s = 0.0;
+        long long last = -1;
+        for(uint32_t it = 0; it < c; ++it)
+        {
+            unsigned long long best = ~0ull; // (rank << 32) | position
+            for(uint32_t j = lane; j < c; j += 64)
+            {
+                const uint32_t r = k[j];
+                if((long long)r > last)
+                    best = min(best, ((unsigned long long)r << 32) | j);
+            }
+#pragma unroll
+            for(int o = 32; o > 0; o >>= 1)
+            {
+                const unsigned long long t = (unsigned long long)__shfl_xor((long long)best, o);
+                best = min(best, t);
+            }
+            s += v[(uint32_t)best];
+            last = (long long)(best >> 32);
+        }
+        if(lane == 0)
+            scores[e] = -s / 2.0;
+    }
+}
+
 // ---- cross-stream exchange format ---------------------------------------------------------
 // One "set" = the BoW vectors of one stream's batch as they travel in the all-gather: for every frame k_max x
 // {u32 word, f32 value} (ascending words, zero padded), then the per-frame word counts:
@@ -888,7 +1063,15 @@ static int bow_load_impl(mslam_hip_ctx* c, const void* blob, size_t size)
     BALLOC(b->d_leaf_desc, (size_t)n_words * 8);
     BALLOC(b->d_leaf_weight, n_words);
     BALLOC(b->d_fbest, (B + 1) * cap);
+    BALLOC(b->ix_head, n_words);
+    BALLOC(b->ix_size, 1);
+    BALLOC(b->ix_total, 1);
 #undef BALLOC
+    if(hipMemset(b->ix_head, 0, (size_t)n_words * 4) != hipSuccess || hipMemset(b->ix_size, 0, 4) != hipSuccess)
+    {
+        c->err = "bow_load: upload failed";
+        return fail_free(MSLAM_HIP_E_RUNTIME);
+    }
     bool ok = hipMemcpy(b->d_desc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(b->d_first, sfirst.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(b->d_nchild, snchild.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -996,6 +1179,96 @@ static int bow_score_dev(mslam_hip_ctx* c, int qslot, int n_frames, long long ba
     return MSLAM_HIP_OK;
 }
 
+// ---- inverted file: host side -----------------------------------------------------------------------------------
+template <typename T>
+static int ix_grow(mslam_hip_ctx* c, T*& ptr, size_t old_n, size_t new_n, bool zero)
+{
+    T* np = nullptr;
+    BHIPCHK(c, bmalloc(np, new_n));
+    if(zero)
+        BHIPCHK(c, hipMemsetAsync(np, 0, new_n * sizeof(T), c->stream));
+    if(ptr && old_n)
+        BHIPCHK(c, hipMemcpyAsync(np, ptr, old_n * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    BHIPCHK(c, hipStreamSynchronize(c->stream));
+    if(ptr)
+        (void)hipFree(ptr);
+    ptr = np;
+    return MSLAM_HIP_OK;
+}
+
+// make room for `max_entries` database entries (postings: max_entries x max_keypoints in the worst case)
+static int ix_reserve(mslam_hip_ctx* c, long long max_entries)
+{
+    BowState* b = c->bow;
+    if(max_entries <= b->ix_max_entries)
+        return MSLAM_HIP_OK;
+    if(max_entries > (1ll << 31) / std::max(b->cap, 1))
+        return bfail(c, MSLAM_HIP_E_CAPACITY, "bow database: more postings than a 32-bit index can address");
+    const size_t old_e = (size_t)b->ix_max_entries, new_e = (size_t)max_entries;
+    const size_t old_p = b->ix_cap_postings ? b->ix_cap_postings + 1 : 0, new_p = new_e * (size_t)b->cap + 1;
+    int rc = 0;
+    rc = rc ? rc : ix_grow(c, b->ix_entry, old_p, new_p, false);
+    rc = rc ? rc : ix_grow(c, b->ix_prev, old_p, new_p, false);
+    rc = rc ? rc : ix_grow(c, b->ix_value, old_p, new_p, false);
+    rc = rc ? rc : ix_grow(c, b->ix_removed, old_e, new_e, true);
+    rc = rc ? rc : ix_grow(c, b->ix_cnt, 0, new_e, true);
+    rc = rc ? rc : ix_grow(c, b->ix_ofs, 0, new_e + 1, true);
+    rc = rc ? rc : ix_grow(c, b->ix_fill, 0, new_e, true);
+    rc = rc ? rc : ix_grow(c, b->ix_scores, 0, new_e, false);
+    rc = rc ? rc : ix_grow(c, b->ix_keys, 0, new_p, false);
+    rc = rc ? rc : ix_grow(c, b->ix_vals, 0, new_p, false);
+    if(rc)
+        return rc;
+    b->ix_max_entries = max_entries;
+    b->ix_cap_postings = new_p - 1;
+    b->ix_cap_terms = new_p;
+    return MSLAM_HIP_OK;
+}
+
+// append the BoW vectors in batch slots [slot0, slot0 + n) as entries next_id .. next_id + n - 1
+static int ix_add(mslam_hip_ctx* c, int slot0, int n)
+{
+    BowState* b = c->bow;
+    if(b->next_id + n > b->ix_max_entries)
+    {
+        const int rc = ix_reserve(c, std::max<long long>(2 * b->ix_max_entries, std::max<long long>(1024, b->next_id + n)));
+        if(rc)
+            return rc;
+    }
+    hipLaunchKernelGGL(k_ix_alloc, dim3(1), dim3(1), 0, c->stream, b->d_bn + slot0, n, b->ix_size, b->ix_ofs,
+                       (uint32_t)b->ix_cap_postings, c->d_flags); // ix_ofs doubles as the per-entry start scratch (n <= B + 1 <= capacity)
+    hipLaunchKernelGGL(k_ix_append, dim3(n), dim3(256), 0, c->stream, b->d_bwords + (size_t)slot0 * b->cap,
+                       b->d_bvalues + (size_t)slot0 * b->cap, b->d_bn + slot0, b->cap, b->next_id, b->ix_ofs, b->ix_size,
+                       (uint32_t)b->ix_cap_postings, b->ix_head, b->ix_entry, b->ix_prev, b->ix_value);
+    BHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
+// score the query vector in batch slot `qslot` against every entry with id < id_limit: ix_scores[e] (-1: no common word)
+static int ix_query(mslam_hip_ctx* c, int qslot, long long id_limit)
+{
+    BowState* b = c->bow;
+    hipStream_t s = c->stream;
+    const long long N = id_limit;
+    BHIPCHK(c, hipMemsetAsync(b->ix_cnt, 0, (size_t)N * 4, s));
+    BHIPCHK(c, hipMemsetAsync(b->ix_fill, 0, (size_t)N * 4, s));
+    const uint32_t* qw = b->d_bwords + (size_t)qslot * b->cap;
+    const double* qv = b->d_bvalues + (size_t)qslot * b->cap;
+    const int32_t* qn = b->d_bn + qslot;
+    const dim3 grid((b->cap + 255) / 256);
+    hipLaunchKernelGGL(k_ix_walk<false>, grid, dim3(256), 0, s, qw, qv, qn, b->ix_head, b->ix_entry, b->ix_prev, b->ix_value,
+                       b->ix_removed, id_limit, b->ix_cnt, b->ix_ofs, b->ix_fill, b->ix_keys, b->ix_vals,
+                       (uint32_t)b->ix_cap_terms);
+    hipLaunchKernelGGL(k_ix_scan, dim3(1), dim3(1024), 0, s, b->ix_cnt, N, b->ix_ofs, b->ix_total);
+    hipLaunchKernelGGL(k_ix_walk<true>, grid, dim3(256), 0, s, qw, qv, qn, b->ix_head, b->ix_entry, b->ix_prev, b->ix_value,
+                       b->ix_removed, id_limit, b->ix_cnt, b->ix_ofs, b->ix_fill, b->ix_keys, b->ix_vals,
+                       (uint32_t)b->ix_cap_terms);
+    const unsigned blocks = (unsigned)std::min<long long>((N + 3) / 4, 4096);
+    hipLaunchKernelGGL(k_ix_sum, dim3(blocks), dim3(256), 0, s, b->ix_cnt, b->ix_ofs, b->ix_keys, b->ix_vals, N, b->ix_scores);
+    BHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
 int bow_batch(mslam_hip_ctx* c, int add_to_db)
 {
     BowState* b = c->bow;
@@ -1010,6 +1283,9 @@ int bow_batch(mslam_hip_ctx* c, int add_to_db)
     {
         hipLaunchKernelGGL(k_bow_commit, dim3(n), dim3(256), 0, c->stream, b->d_bwords, b->d_bvalues, b->d_bn, b->cap,
                            b->next_id, b->RP, b->d_rwords, b->d_rvalues, b->d_rn);
+        rc = ix_add(c, 0, n); // the inverted file sees the batch's entries too (host-side queries are unbounded)
+        if(rc)
+            return rc;
     }
     rc = bow_score_dev(c, 0, n, b->next_id, add_to_db ? 1 : 0);
     if(rc)
@@ -1168,6 +1444,9 @@ int mslam_hip_bow_db_add(mslam_hip_ctx* c, const uint8_t* desc, int n, int* entr
     hipLaunchKernelGGL(k_bow_commit, dim3(1), dim3(256), 0, c->stream, b->d_bwords + o, b->d_bvalues + o, b->d_bn + b->B,
                        b->cap, b->next_id, b->RP, b->d_rwords, b->d_rvalues, b->d_rn);
     BHIPCHK(c, hipGetLastError());
+    rc = ix_add(c, b->B, 1);
+    if(rc)
+        return rc;
     BHIPCHK(c, hipStreamSynchronize(c->stream));
     if(entry_id)
         *entry_id = (int)b->next_id;
@@ -1188,20 +1467,20 @@ int mslam_hip_bow_db_query(mslam_hip_ctx* c, const uint8_t* desc, int n, int max
     rc = host_transform(c, desc, n);
     if(rc)
         return rc;
-    rc = bow_score_dev(c, b->B, 1, b->next_id, 0);
+    // Database::queryL1 over the inverted file: every entry ever added (and not removed) that shares a word
+    const long long N = b->next_id;
+    if(N == 0)
+        return MSLAM_HIP_OK;
+    rc = ix_query(c, b->B, N);
     if(rc)
         return rc;
-    std::vector<double> sc(b->R);
-    BHIPCHK(c, hipMemcpyAsync(sc.data(), b->d_scores + (size_t)b->B * b->R, (size_t)b->R * 8, hipMemcpyDeviceToHost,
-                              c->stream));
+    std::vector<double> sc((size_t)N);
+    BHIPCHK(c, hipMemcpyAsync(sc.data(), b->ix_scores, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
     BHIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<std::pair<double, long long>> res;
-    for(int j = 0; j < b->R; ++j)
-    {
-        const long long id = b->next_id - 1 - j;
-        if(id >= 0 && sc[j] >= 0)
-            res.emplace_back(sc[j], id);
-    }
+    for(long long id = 0; id < N; ++id)
+        if(sc[(size_t)id] >= 0)
+            res.emplace_back(sc[(size_t)id], id);
     std::sort(res.begin(), res.end(), [](const auto& x, const auto& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
     const int m = std::min<int>(max_results, (int)res.size());
     for(int i = 0; i < m; ++i)
@@ -1234,10 +1513,10 @@ int mslam_hip_bow_db_remove(mslam_hip_ctx* c, int entry_id)
     BowState* b = c->bow;
     if(entry_id < 0 || entry_id >= b->next_id)
         return bfail(c, MSLAM_HIP_E_INVALID, "bow_db_remove: no such entry");
-    if(entry_id < b->next_id - b->R)
-        return MSLAM_HIP_OK; // already out of the window
-    // an entry without words shares no word with any query: Database::query never reports it
-    BHIPCHK(c, hipMemsetAsync(b->d_rn + (entry_id % b->RP), 0, 4, c->stream));
+    BHIPCHK(c, hipMemsetAsync(b->ix_removed + entry_id, 1, 1, c->stream)); // its postings are skipped from now on
+    if(entry_id >= b->next_id - b->R)
+        // the batched path's window: an entry without words shares no word with any query
+        BHIPCHK(c, hipMemsetAsync(b->d_rn + (entry_id % b->RP), 0, 4, c->stream));
     return MSLAM_HIP_OK;
 }
 
@@ -1248,7 +1527,31 @@ int mslam_hip_bow_db_clear(mslam_hip_ctx* c)
         return rc;
     BHIPCHK(c, hipStreamSynchronize(c->stream));
     BHIPCHK(c, hipMemset(c->bow->d_rn, 0, (size_t)c->bow->RP * 4));
+    BHIPCHK(c, hipMemset(c->bow->ix_head, 0, (size_t)c->bow->n_words * 4));
+    BHIPCHK(c, hipMemset(c->bow->ix_size, 0, 4));
+    if(c->bow->ix_removed)
+        BHIPCHK(c, hipMemset(c->bow->ix_removed, 0, (size_t)c->bow->ix_max_entries));
     c->bow->next_id = 0;
+    return MSLAM_HIP_OK;
+}
+
+int mslam_hip_bow_db_reserve(mslam_hip_ctx* c, int max_entries)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    if(max_entries < 1)
+        return bfail(c, MSLAM_HIP_E_INVALID, "bow_db_reserve: bad argument");
+    return ix_reserve(c, max_entries);
+}
+
+int mslam_hip_bow_db_size(mslam_hip_ctx* c, int* n_entries)
+{
+    int rc = need_voc(c);
+    if(rc)
+        return rc;
+    if(n_entries)
+        *n_entries = (int)c->bow->next_id;
     return MSLAM_HIP_OK;
 }
 

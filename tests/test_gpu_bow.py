@@ -237,9 +237,11 @@ def test_cfg3_million_word_vocabulary(pkg, orc, descs):
     c.close()
 
 
-def test_database_window_wraps(pkg, orc):
-    """the database keeps the most recent entries in a ring: 150 host-side adds and 50 batches of 3 frames wrap the
-    ring more than twice; every query must equal the oracle's model of "the last 64 entries"."""
+def test_database_inverted_file_and_batch_window(pkg, orc):
+    """host side: the database is an unbounded inverted file (DBoW3::Database(voc, false, 0), orb_relocalizer.cpp:29):
+    300 adds (the storage grows past its first reservation of 64), queries against EVERY entry, removals.
+    Batched device path: every frame is scored against the 64 entries that precede it (cfg3); 50 batches of 3 wrap
+    that window more than twice, and its entries land in the same inverted file."""
     import torch
     blob = synth.make_vocabulary(10, 3)
     V = orc.Vocabulary(blob)
@@ -249,19 +251,30 @@ def test_database_window_wraps(pkg, orc):
     rng = np.random.default_rng(21)
     pool = rng.integers(0, 256, (40, 300, 32), dtype=np.uint8)      # 40 descriptor sets that share words
     sets, vecs = [], []
-    for t in range(150):
+    n_add = 300
+    for t in range(n_add):
         d = pool[rng.integers(0, 40)].copy()
         d[:rng.integers(1, 200)] = rng.integers(0, 256, (1, 32), dtype=np.uint8)
         sets.append(d)
         vecs.append(V.bow_vector(d))
-    for t in range(150):
-        if t % 7 == 0 or t > 140:
-            ids, sc = c.bow_db_query(sets[t], 64)
-            exp = sorted(((orc.bow_score_l1(*vecs[t], *vecs[e]), e) for e in range(max(0, t - 64), t)),
-                         key=lambda x: (-x[0], x[1]))
-            exp = [x for x in exp if x[0] > 0]
+    c.bow_db_reserve(64)
+    removed = set()
+
+    def model(t, live):
+        exp = sorted(((orc.bow_score_l1(*vecs[t], *vecs[e]), e) for e in live), key=lambda x: (-x[0], x[1]))
+        return [x for x in exp if x[0] > 0]
+    for t in range(n_add):
+        if t % 13 == 0 or t > n_add - 8:
+            ids, sc = c.bow_db_query(sets[t], n_add)
+            exp = model(t, [e for e in range(t) if e not in removed])
             assert list(ids) == [e for _, e in exp] and list(sc) == [s for s, _ in exp], t
-        assert c.bow_db_add(sets[t]) == t
+        assert c.bow_db_add(sets[t]) == t and c.bow_db_size() == t + 1
+        if t in (40, 41, 170):
+            c.bow_db_remove(t - 7)                                  # IRelocalizer::removeKeyframe
+            removed.add(t - 7)
+    ids, sc = c.bow_db_query(sets[5], 10)                           # top-10 of 300, an entry of the database itself
+    exp = model(5, [e for e in range(n_add) if e not in removed])[:10]
+    assert list(ids) == [e for _, e in exp] and list(sc) == [s for s, _ in exp] and ids[0] == 5 and sc[0] > 0.999
     c.bow_db_clear()
     # batched path: frames cycle with period 5 (not a divisor of the batch size), so equal scores occur inside the
     # window and the tie rule (lower entry id) is exercised across the wrap
@@ -280,6 +293,14 @@ def test_database_window_wraps(pkg, orc):
         for i in range(3):
             exp = _l1_model_best(orc, fv, 3 * b + i)
             assert (be[i], bs[i]) == ((exp[1], exp[0]) if exp else (-1, 0.0)), (b, i)
+    # the 150 batch entries are in the inverted file: a host query sees all of them, not just the last 64
+    assert c.bow_db_size() == 150
+    q = orc.detect(frames[2], orc.params())["desc"]
+    ids, sc = c.bow_db_query(q, 150)
+    exp = sorted(((orc.bow_score_l1(*fv5[2], *fv[e]), e) for e in range(150)), key=lambda x: (-x[0], x[1]))
+    exp = [x for x in exp if x[0] > 0]
+    assert list(ids) == [e for _, e in exp] and list(sc) == [s for s, _ in exp]
+    assert sum(1 for s in sc if s > 0.999) == order.count(2) > 20      # every revisit of frame 2, old ones included
     c.close()
 
 
