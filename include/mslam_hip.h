@@ -147,7 +147,8 @@ int mslam_hip_get_matcher(const mslam_hip_ctx* ctx);
  * Replaces what OrbRelocalizer is wired for (orb_relocalizer.cpp:26-50, relocalizer.hpp:11-20,
  * loop_detection.hpp:10-15): DBoW3::Vocabulary::transform and Database add/query with L1 scoring.
  * `blob` is a DBoW3 binary vocabulary stream (Vocabulary::toStream/fromStream,
- * conan_recipes/dbow3/dbow3.patch:2252-2355,2544-2651), uncompressed. */
+ * conan_recipes/dbow3/dbow3.patch:2252-2355,2544-2651), plain or saved with compressed = true (QuickLZ 1.5 packets,
+ * levels 1 and 3; the decoder is a restatement of the published format, see csrc/quicklz_decode.hip). */
 enum /* DBoW3 WeightingType / ScoringType as stored in the vocabulary stream */
 {
     MSLAM_BOW_TF_IDF = 0,
@@ -239,6 +240,11 @@ int mslam_hip_bow_cross_score_dev(mslam_hip_ctx* ctx, const uint32_t* d_words, c
 int mslam_hip_bow_pack_dev(mslam_hip_ctx* ctx, int k_max, uint32_t* d_out);
 int mslam_hip_bow_cross_score_packed_dev(mslam_hip_ctx* ctx, const uint32_t* d_sets, int n_sets, int self_set,
                                          int n_frames, int k_max, double* d_scores, void* stream);
+
+/* Host-only helper (no GPU, no context): decode `n_packets` consecutive QuickLZ packets, as DBoW3 writes them after the
+ * nChunks word of a compressed vocabulary.  dst_size receives the decoded size (also when dst is too small). */
+int mslam_hip_qlz_decompress(const void* src, size_t src_size, uint32_t n_packets, void* dst, size_t dst_capacity,
+                             size_t* dst_size);
 
 /* ---- RGB-D back-projection (the step after the matcher) ----------------------------
  * Replaces pointsFromRgbdKeypoints / reconstructPoint (rgbd_feature_frontend.cpp:101-138) with getDepth /

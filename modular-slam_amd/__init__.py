@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "mslam_hip_get_points_view", "mslam_hip_set_matcher", "mslam_hip_get_matcher",
     "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
-    "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size",
+    "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size", "mslam_hip_qlz_decompress",
 ]
 
 
@@ -357,6 +357,20 @@ class Context:
         n = C.c_int(0)
         self._chk(self.L.mslam_hip_get_stage_times(self._h, names, ms, cap, C.byref(n)))
         return [(names[i].decode(), ms[i]) for i in range(n.value)]
+
+
+def qlz_decompress(data, n_packets, capacity=None):
+    """host-only: decode consecutive QuickLZ packets (what follows nChunks in a compressed DBoW3 vocabulary)"""
+    src = np.frombuffer(bytes(data), np.uint8)
+    cap = capacity if capacity is not None else 10000 * n_packets + 16
+    dst = np.empty(max(cap, 1), np.uint8)
+    n = C.c_size_t(0)
+    L = lib()
+    L.mslam_hip_qlz_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    rc = L.mslam_hip_qlz_decompress(_p(src), src.size, int(n_packets), _p(dst), dst.size, C.byref(n))
+    if rc != OK:
+        raise MslamHipError(rc, "qlz_decompress failed")
+    return dst[:n.value].tobytes()
 
 
 # ---- mirrors of the reference plugin interfaces ---------------------------------------------------

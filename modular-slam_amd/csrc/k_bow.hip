@@ -23,6 +23,7 @@
 
 namespace mslam
 {
+int qlz_decode_stream(const uint8_t* src, size_t size, uint32_t n_packets, std::vector<uint8_t>& out); // quicklz_decode.hip
 
 constexpr int kBowGroup = 16; // lanes cooperating on one descriptor: one child each, <= 16 per step
 
@@ -928,8 +929,17 @@ static int bow_load_impl(mslam_hip_ctx* c, const void* blob, size_t size)
     const uint32_t n_nodes = r.get<uint32_t>();
     if(!r.ok || n_nodes == 0)
         return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: empty vocabulary");
+    std::vector<uint8_t> body; // the decompressed stream when the file was saved with compressed = true
     if(compressed)
-        return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: QuickLZ-compressed streams are not supported; save with compressed=false");
+    {
+        // dbow3.patch:2594-2611: u32 nChunks, then one QuickLZ packet per 10 000 bytes of the stream below
+        const uint32_t n_chunks = r.get<uint32_t>();
+        if(!r.ok || qlz_decode_stream(r.p + r.pos, size - r.pos, n_chunks, body) != MSLAM_HIP_OK)
+            return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: cannot decode the QuickLZ packets of a compressed vocabulary "
+                                                "(levels 1 and 3 of QuickLZ 1.5 are handled)");
+        r = Reader{body.data(), body.size()};
+        size = body.size();
+    }
     const int k = r.get<int32_t>(), L = r.get<int32_t>(), scoring = r.get<int32_t>(), weighting = r.get<int32_t>();
     if(!r.ok || k < 1 || weighting < 0 || weighting > 3 || scoring < 0 || scoring > 5)
         return bfail(c, MSLAM_HIP_E_FORMAT, "bow_load: bad header");
