@@ -29,7 +29,8 @@ enum
     MSLAM_HIP_E_RUNTIME = 2,  /* HIP runtime failure (no device, launch failure, OOM...) */
     MSLAM_HIP_E_CAPACITY = 3, /* an output or scratch capacity was exceeded; no partial result is valid */
     MSLAM_HIP_E_NO_VOCABULARY = 4,
-    MSLAM_HIP_E_FORMAT = 5 /* vocabulary stream not understood */
+    MSLAM_HIP_E_FORMAT = 5,   /* vocabulary stream not understood */
+    MSLAM_HIP_E_NO_MODEL = 6  /* RANSAC found no model (cv::solvePnPRansac returning false) */
 };
 
 typedef struct mslam_hip_ctx mslam_hip_ctx;
@@ -265,6 +266,21 @@ typedef struct
     const uint8_t* valid; /* [max_batch][capacity]           */
 } mslam_hip_points_view;
 int mslam_hip_get_points_view(mslam_hip_ctx* ctx, mslam_hip_points_view* view);
+
+/* ---- IPnpAlgorithm::solvePnp (the consumer of the matches) ------------------------------------
+ * Replaces OpenCvRansacPnp::solvePnp's cv::solvePnPRansac call (cv_ransac_pnp.cpp:56-57: useExtrinsicGuess = true, 100
+ * iterations, 5 px, confidence 0.99, no distortion).  object_points = n x 3 f32 (landmark states cast to float, :22-31),
+ * image_points = n x 2 f32 (:33-40), pin-hole intrinsics as in :52-53.  rvec / tvec (3 doubles each, Rodrigues vector
+ * and translation of the world -> camera transform, OpenCV's convention) are the extrinsic guess on input when
+ * use_extrinsic_guess is non-zero, and the result on output; inliers (n bytes, may be NULL) is the consensus mask of
+ * the best hypothesis.  Returns MSLAM_HIP_E_NO_MODEL when no hypothesis reaches 4 inliers (solvePnPRansac == false).
+ * The minimal solver, sampling and refinement are this library's own (P3P, splitmix64 with `seed`, damped
+ * Gauss-Newton): see csrc/k_pnp.hip for what is and is not the same as OpenCV's internals.  The confidence bound only
+ * ends OpenCV's loop early; here all `iterations` hypotheses are scored in one launch. */
+int mslam_hip_pnp_ransac(mslam_hip_ctx* ctx, const float* object_points, const float* image_points, int n, double fx,
+                         double fy, double cx, double cy, int use_extrinsic_guess, int iterations,
+                         double reprojection_error, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers,
+                         int* n_inliers);
 
 /* ---- test / debug access to intermediate stages (host copies; synchronises) -----------------------*/
 enum

@@ -20,9 +20,19 @@
 #define MSLAM_HD static inline
 #endif
 
+MSLAM_HD void mslam_sincos_f64(double x, double* s_out, double* c_out);
+
 MSLAM_HD void mslam_sincos_f32(float xf, float* s_out, float* c_out)
 {
-    const double x = (double)xf;
+    double s, c;
+    mslam_sincos_f64((double)xf, &s, &c);
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+/* the double-precision evaluation itself (|x| <= 8; absolute error < 1e-15); also used by the PnP refinement */
+MSLAM_HD void mslam_sincos_f64(double x, double* s_out, double* c_out)
+{
     const double two_over_pi = 0.63661977236758134308;
     const double pio2_hi = 1.57079632679489655800e+00; /* pi/2 rounded to double            */
     const double pio2_lo = 6.12323399573676603587e-17; /* pi/2 - pio2_hi                    */
@@ -57,8 +67,8 @@ MSLAM_HD void mslam_sincos_f32(float xf, float* s_out, float* c_out)
     case 2: sr = -s, cr = -c; break;
     default: sr = -c, cr = s; break;
     }
-    *s_out = (float)sr;
-    *c_out = (float)cr;
+    *s_out = sr;
+    *c_out = cr;
 }
 
 #endif /* MSLAM_SINCOS_H_ */

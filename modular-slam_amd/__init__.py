@@ -23,7 +23,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmslam_hip.so")
 
-OK, E_INVALID, E_RUNTIME, E_CAPACITY, E_NO_VOCABULARY, E_FORMAT = range(6)
+OK, E_INVALID, E_RUNTIME, E_CAPACITY, E_NO_VOCABULARY, E_FORMAT, E_NO_MODEL = range(7)
 DBG_PYRAMID, DBG_BLURRED, DBG_CANDIDATES, DBG_SELECTED = range(4)
 MATCHER_AUTO, MATCHER_POPCOUNT = 0, 1
 DETECTOR_DISTRIBUTED, DETECTOR_CV_ORB = 0, 1
@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
     "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size", "mslam_hip_qlz_decompress",
+    "mslam_hip_pnp_ransac",
 ]
 
 
@@ -230,6 +231,27 @@ class Context:
         v = PointsView()
         self._chk(self.L.mslam_hip_get_points_view(self._h, C.byref(v)))
         return v
+
+    # ---- PnP RANSAC (cv_ransac_pnp.cpp:14-85) ---------------------------------------------------
+    def pnp_ransac(self, object_points, image_points, focal=(525.0, 525.0), principal=(319.5, 239.5), rvec=None,
+                   tvec=None, iterations=100, reprojection_error=5.0, seed=0):
+        """-> (rvec[3], tvec[3], inlier mask[n]) of the world -> camera transform, or None when no model was found
+        (cv::solvePnPRansac returning false).  rvec/tvec given = useExtrinsicGuess."""
+        obj = np.ascontiguousarray(object_points, np.float32).reshape(-1, 3)
+        img = np.ascontiguousarray(image_points, np.float32).reshape(-1, 2)
+        guess = rvec is not None and tvec is not None
+        r = np.array(rvec if guess else (0, 0, 0), np.float64)
+        t = np.array(tvec if guess else (0, 0, 0), np.float64)
+        mask = np.zeros(len(obj), np.uint8)
+        n_in = C.c_int(0)
+        rc = self.L.mslam_hip_pnp_ransac(self._h, _p(obj), _p(img), len(obj), C.c_double(focal[0]), C.c_double(focal[1]),
+                                         C.c_double(principal[0]), C.c_double(principal[1]), int(guess), int(iterations),
+                                         C.c_double(reprojection_error), C.c_uint64(seed), _p(r), _p(t), _p(mask),
+                                         C.byref(n_in))
+        if rc == E_NO_MODEL:
+            return None
+        self._chk(rc)
+        return r, t, mask.astype(bool)
 
     # ---- bag of words --------------------------------------------------------------------------
     def bow_load(self, blob):

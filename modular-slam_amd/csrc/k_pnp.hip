@@ -1,0 +1,671 @@
+// k_pnp.hip — RANSAC PnP: the consumer of the matches.
+//
+// Replaces OpenCvRansacPnp::solvePnp (reference cv_ransac_pnp.cpp:14-85), i.e.
+//   cv::solvePnPRansac(objectPoints f32, imagePoints f32, K, noArray(), rvec, tvec, useExtrinsicGuess = true,
+//                      iterationsCount = 100, reprojectionError = 5.0, confidence = 0.99, inliers)   (:56-57)
+// Contract kept: pin-hole camera without distortion, at most `iterations` hypotheses from random minimal samples, a
+// point is an inlier iff its squared reprojection error is <= reprojectionError^2, the pose returned is refined on the
+// consensus set of the best hypothesis (most inliers, first on ties) starting from the caller's guess when
+// useExtrinsicGuess is set, and the inlier mask is that of the best hypothesis.
+// What differs from OpenCV's internals (not in the reference tree; parity with it is UNPINNED — DESIGN.md): the minimal
+// solver is P3P (Grunert's quartic, 3 points + 1 to disambiguate) instead of EPnP on 5 points, samples come from a
+// counter-based generator (splitmix64) instead of cv::RNG, all hypotheses are always evaluated (no early exit on the
+// confidence bound), and the refinement is a damped Gauss-Newton on (rotation, translation) instead of
+// cvFindExtrinsicCameraParams2's LM on (rvec, tvec).  tests/ pin it against ground-truth poses and an independent
+// numpy oracle.
+//
+// One workgroup solves one problem: hypotheses are generated one per thread, scored against every point by the
+// whole workgroup, and the refinement's normal equations are reduced in a fixed order (bit-reproducible).
+// All arithmetic is f64: + - * / sqrt and include/mslam_sincos.h.
+#include "context.hpp"
+#include "../../include/mslam_sincos.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mslam
+{
+
+struct PnpArgs
+{
+    const float* obj; // [n][3]
+    const float* img; // [n][2]
+    int n;
+    double fx, fy, cx, cy;
+    double R0[9], t0[3]; // the caller's guess (use_guess)
+    int use_guess;
+    int iterations;
+    double thr2; // reprojectionError^2
+    unsigned long long seed;
+    double* hyp;     // [iterations][12] R (row major), t
+    int32_t* counts; // [iterations]
+    uint8_t* mask;   // [n]
+    double* out;     // R[9], t[3], n_inliers, best hypothesis, status
+};
+
+__device__ __forceinline__ unsigned long long splitmix(unsigned long long& x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct V3
+{
+    double x, y, z;
+};
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3 mulR(const double* R, V3 p)
+{
+    return v3(R[0] * p.x + R[1] * p.y + R[2] * p.z, R[3] * p.x + R[4] * p.y + R[5] * p.z, R[6] * p.x + R[7] * p.y + R[8] * p.z);
+}
+
+// orthonormal frame of a triangle: e1 along (b - a), e3 normal, e2 = e3 x e1; false when degenerate
+__device__ bool tri_frame(V3 a, V3 b, V3 c, V3& e1, V3& e2, V3& e3)
+{
+    const V3 ab = b - a, ac = c - a;
+    const double l1 = sqrt(dot(ab, ab));
+    if(!(l1 > 1e-12))
+        return false;
+    e1 = (1.0 / l1) * ab;
+    const V3 nrm = cross(e1, ac);
+    const double l3 = sqrt(dot(nrm, nrm));
+    if(!(l3 > 1e-12))
+        return false;
+    e3 = (1.0 / l3) * nrm;
+    e2 = cross(e3, e1);
+    return true;
+}
+
+// real roots of x^4 + a x^3 + b x^2 + c x + d (Ferrari; the resolvent root by bisection, roots polished by Newton)
+__device__ int quartic_roots(double a, double b, double c, double d, double* roots)
+{
+    const double a2 = a * a;
+    const double p = b - 0.375 * a2;
+    const double q = c - 0.5 * a * b + 0.125 * a2 * a;
+    const double r = d - 0.25 * a * c + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
+    int n = 0;
+    double y[4];
+    const double tiny = 1e-14 * (1.0 + fabs(p) * sqrt(fabs(p)) + fabs(q));
+    if(fabs(q) <= tiny)
+    {
+        // biquadratic: y^2 = (-p +- sqrt(p^2 - 4 r)) / 2
+        const double disc = p * p - 4.0 * r;
+        if(disc >= 0.0)
+        {
+            const double sq = sqrt(disc);
+            const double z0 = 0.5 * (-p + sq), z1 = 0.5 * (-p - sq);
+            if(z0 >= 0.0)
+                y[n++] = sqrt(z0), y[n++] = -sqrt(z0);
+            if(z1 >= 0.0)
+                y[n++] = sqrt(z1), y[n++] = -sqrt(z1);
+        }
+    }
+    else
+    {
+        // a positive root m of m^3 + p m^2 + (p^2/4 - r) m - q^2/8: g(0) < 0, g(M) > 0
+        const double c1 = 0.25 * p * p - r, c0 = -0.125 * q * q;
+        double lo = 0.0, hi = 1.0 + fmax(fabs(p), fmax(fabs(c1), fabs(c0)));
+        for(int it = 0; it < 100; ++it)
+        {
+            const double m = 0.5 * (lo + hi);
+            const double g = ((m + p) * m + c1) * m + c0;
+            if(g > 0.0)
+                hi = m;
+            else
+                lo = m;
+        }
+        const double m = 0.5 * (lo + hi);
+        const double s = sqrt(2.0 * m);
+        const double h = q / (2.0 * s);
+        const double k0 = 0.5 * p + m;
+        // y^2 - s y + (k0 + h) = 0 and y^2 + s y + (k0 - h) = 0
+        const double d1 = s * s - 4.0 * (k0 + h), d2 = s * s - 4.0 * (k0 - h);
+        if(d1 >= 0.0)
+        {
+            const double sq = sqrt(d1);
+            y[n++] = 0.5 * (s + sq), y[n++] = 0.5 * (s - sq);
+        }
+        if(d2 >= 0.0)
+        {
+            const double sq = sqrt(d2);
+            y[n++] = 0.5 * (-s + sq), y[n++] = 0.5 * (-s - sq);
+        }
+    }
+    for(int i = 0; i < n; ++i)
+    {
+        double x = y[i] - 0.25 * a;
+        for(int it = 0; it < 3; ++it)
+        {
+            const double f = (((x + a) * x + b) * x + c) * x + d;
+            const double fp = ((4.0 * x + 3.0 * a) * x + 2.0 * b) * x + c;
+            if(fp != 0.0)
+                x -= f / fp;
+        }
+        roots[i] = x;
+    }
+    return n;
+}
+
+struct Cam
+{
+    double fx, fy, cx, cy;
+};
+
+__device__ __forceinline__ bool project(const Cam& k, const double* R, const double* t, V3 P, double& u, double& v)
+{
+    const V3 X = mulR(R, P) + v3(t[0], t[1], t[2]);
+    if(!(X.z > 1e-9))
+        return false;
+    u = k.fx * X.x / X.z + k.cx;
+    v = k.fy * X.y / X.z + k.cy;
+    return true;
+}
+
+// P3P on points 0..2 of the sample (Grunert's quartic), the 4th point picks among the solutions
+__device__ bool p3p_hypothesis(const Cam& k, const V3* P, const double* uv, double* R, double* t)
+{
+    V3 f[3];
+    for(int i = 0; i < 3; ++i)
+    {
+        const V3 d = v3((uv[2 * i] - k.cx) / k.fx, (uv[2 * i + 1] - k.cy) / k.fy, 1.0);
+        f[i] = (1.0 / sqrt(dot(d, d))) * d;
+    }
+    const V3 d23 = P[1] - P[2], d13 = P[0] - P[2], d12 = P[0] - P[1];
+    const double a2 = dot(d23, d23), b2 = dot(d13, d13), c2 = dot(d12, d12);
+    if(!(a2 > 1e-18 && b2 > 1e-18 && c2 > 1e-18))
+        return false;
+    const double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
+    const double k1 = (a2 - c2) / b2, k2 = (a2 + c2) / b2;
+    const double A4 = (k1 - 1.0) * (k1 - 1.0) - 4.0 * c2 / b2 * ca * ca;
+    const double A3 = 4.0 * (k1 * (1.0 - k1) * cb - (1.0 - k2) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb);
+    const double A2 = 2.0 * (k1 * k1 - 1.0 + 2.0 * k1 * k1 * cb * cb + 2.0 * ((b2 - c2) / b2) * ca * ca - 4.0 * k2 * ca * cb * cg +
+                             2.0 * ((b2 - a2) / b2) * cg * cg);
+    const double A1 = 4.0 * (-k1 * (1.0 + k1) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - k2) * ca * cg);
+    const double A0 = (1.0 + k1) * (1.0 + k1) - 4.0 * a2 / b2 * cg * cg;
+    if(!(fabs(A4) > 1e-14))
+        return false;
+    double roots[4];
+    const int nr = quartic_roots(A3 / A4, A2 / A4, A1 / A4, A0 / A4, roots);
+    V3 e1, e2, e3;
+    if(!tri_frame(P[0], P[1], P[2], e1, e2, e3))
+        return false;
+    double best = 1e300;
+    bool found = false;
+    for(int i = 0; i < nr; ++i)
+    {
+        const double v = roots[i];
+        const double den = 2.0 * (cg - v * ca);
+        if(!(v > 0.0) || !(fabs(den) > 1e-14))
+            continue;
+        const double u = ((k1 - 1.0) * v * v - 2.0 * k1 * cb * v + 1.0 + k1) / den;
+        const double s1d = 1.0 + v * v - 2.0 * v * cb;
+        if(!(u > 0.0) || !(s1d > 1e-14))
+            continue;
+        const double s1 = sqrt(b2 / s1d);
+        const V3 X0 = s1 * f[0], X1 = (u * s1) * f[1], X2 = (v * s1) * f[2];
+        V3 g1, g2, g3;
+        if(!tri_frame(X0, X1, X2, g1, g2, g3))
+            continue;
+        // R maps the world triangle frame onto the camera one: R = [g1 g2 g3] [e1 e2 e3]^T
+        double Rc[9];
+        Rc[0] = g1.x * e1.x + g2.x * e2.x + g3.x * e3.x, Rc[1] = g1.x * e1.y + g2.x * e2.y + g3.x * e3.y, Rc[2] = g1.x * e1.z + g2.x * e2.z + g3.x * e3.z;
+        Rc[3] = g1.y * e1.x + g2.y * e2.x + g3.y * e3.x, Rc[4] = g1.y * e1.y + g2.y * e2.y + g3.y * e3.y, Rc[5] = g1.y * e1.z + g2.y * e2.z + g3.y * e3.z;
+        Rc[6] = g1.z * e1.x + g2.z * e2.x + g3.z * e3.x, Rc[7] = g1.z * e1.y + g2.z * e2.y + g3.z * e3.y, Rc[8] = g1.z * e1.z + g2.z * e2.z + g3.z * e3.z;
+        const V3 tt = X0 - mulR(Rc, P[0]);
+        const double tc[3] = {tt.x, tt.y, tt.z};
+        double pu, pv;
+        if(!project(k, Rc, tc, P[3], pu, pv))
+            continue;
+        const double e = (pu - uv[6]) * (pu - uv[6]) + (pv - uv[7]) * (pv - uv[7]);
+        if(e < best)
+        {
+            best = e;
+            found = true;
+            for(int j = 0; j < 9; ++j)
+                R[j] = Rc[j];
+            t[0] = tc[0], t[1] = tc[1], t[2] = tc[2];
+        }
+    }
+    return found;
+}
+
+constexpr int kPnpThreads = 256;
+
+// fixed-order workgroup sum of `cnt` doubles per thread (acc[cnt]); the totals land in red[0..cnt)
+__device__ void wg_sum(double* acc, int cnt, double* red /*[cnt][kPnpThreads]*/, int tid)
+{
+    for(int j = 0; j < cnt; ++j)
+        red[j * kPnpThreads + tid] = acc[j];
+    __syncthreads();
+    for(int o = kPnpThreads / 2; o > 0; o >>= 1)
+    {
+        if(tid < o)
+            for(int j = 0; j < cnt; ++j)
+                red[j * kPnpThreads + tid] += red[j * kPnpThreads + tid + o];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
+{
+    extern __shared__ double red[]; // [28][kPnpThreads]
+    __shared__ int s_best, s_cnt;
+    __shared__ double sR[9], st[3], sNew[12];
+    __shared__ double s_lambda, s_cost;
+    __shared__ int s_stop;
+    const int tid = threadIdx.x;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy};
+    const int n = a.n;
+
+    // ---- 1. hypotheses: thread h draws 4 distinct points and solves P3P
+    for(int h = tid; h < a.iterations; h += kPnpThreads)
+    {
+        unsigned long long x = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(h + 1);
+        int idx[4];
+        bool ok = n >= 4;
+        for(int k = 0; k < 4 && ok; ++k)
+        {
+            int tries = 0;
+            for(;;)
+            {
+                idx[k] = (int)(splitmix(x) % (unsigned long long)n);
+                bool dup = false;
+                for(int j = 0; j < k; ++j)
+                    dup = dup || idx[j] == idx[k];
+                if(!dup)
+                    break;
+                if(++tries > 64)
+                {
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        double R[9], t[3];
+        if(ok)
+        {
+            V3 P[4];
+            double uv[8];
+            for(int k = 0; k < 4; ++k)
+            {
+                P[k] = v3((double)a.obj[3 * idx[k]], (double)a.obj[3 * idx[k] + 1], (double)a.obj[3 * idx[k] + 2]);
+                uv[2 * k] = (double)a.img[2 * idx[k]];
+                uv[2 * k + 1] = (double)a.img[2 * idx[k] + 1];
+            }
+            ok = p3p_hypothesis(cam, P, uv, R, t);
+        }
+        double* hp = a.hyp + (size_t)h * 12;
+        for(int j = 0; j < 9; ++j)
+            hp[j] = ok ? R[j] : 0.0;
+        for(int j = 0; j < 3; ++j)
+            hp[9 + j] = ok ? t[j] : 0.0;
+        a.counts[h] = ok ? 0 : -1;
+    }
+    __syncthreads();
+
+    // ---- 2. score every hypothesis against every point: wave w takes hypotheses w, w+4, ...
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for(int h = wave; h < a.iterations; h += kPnpThreads / 64)
+        {
+            if(a.counts[h] < 0)
+                continue;
+            const double* hp = a.hyp + (size_t)h * 12;
+            int c = 0;
+            for(int i = lane; i < n; i += 64)
+            {
+                double u, v;
+                const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
+                if(project(cam, hp, hp + 9, P, u, v))
+                {
+                    const double du = u - (double)a.img[2 * i], dv = v - (double)a.img[2 * i + 1];
+                    c += (du * du + dv * dv <= a.thr2) ? 1 : 0;
+                }
+            }
+            for(int o = 32; o > 0; o >>= 1)
+                c += __shfl_xor(c, o);
+            if(lane == 0)
+                a.counts[h] = c;
+        }
+    }
+    __syncthreads();
+    if(tid == 0)
+    {
+        int best = -1, bc = -1;
+        for(int h = 0; h < a.iterations; ++h)
+            if(a.counts[h] > bc)
+                bc = a.counts[h], best = h;
+        s_best = best;
+        s_cnt = bc;
+    }
+    __syncthreads();
+    const int best = s_best;
+    if(best < 0 || s_cnt < 4)
+    {
+        if(tid == 0)
+        {
+            for(int j = 0; j < 12; ++j)
+                a.out[j] = 0.0;
+            a.out[12] = 0.0, a.out[13] = -1.0, a.out[14] = 0.0; // status 0: no model
+        }
+        for(int i = tid; i < n; i += kPnpThreads)
+            a.mask[i] = 0;
+        return;
+    }
+    // ---- 3. consensus set of the best hypothesis
+    {
+        const double* hp = a.hyp + (size_t)best * 12;
+        for(int i = tid; i < n; i += kPnpThreads)
+        {
+            double u, v;
+            const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
+            bool in = false;
+            if(project(cam, hp, hp + 9, P, u, v))
+            {
+                const double du = u - (double)a.img[2 * i], dv = v - (double)a.img[2 * i + 1];
+                in = du * du + dv * dv <= a.thr2;
+            }
+            a.mask[i] = in ? 1 : 0;
+        }
+        if(tid < 9)
+            sR[tid] = a.use_guess ? a.R0[tid] : hp[tid];
+        if(tid < 3)
+            st[tid] = a.use_guess ? a.t0[tid] : hp[9 + tid];
+        if(tid == 0)
+            s_lambda = 1e-3, s_stop = 0;
+    }
+    __syncthreads();
+
+    // ---- 4. damped Gauss-Newton on the consensus set: X = exp(w) R P + t + dt
+    auto cost_of = [&](const double* R, const double* t) -> double {
+        double c = 0.0;
+        for(int i = tid; i < n; i += kPnpThreads)
+            if(a.mask[i])
+            {
+                double u, v;
+                const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
+                if(project(cam, R, t, P, u, v))
+                {
+                    const double du = u - (double)a.img[2 * i], dv = v - (double)a.img[2 * i + 1];
+                    c += du * du + dv * dv;
+                }
+                else
+                    c += 1e12; // behind the camera
+            }
+        wg_sum(&c, 1, red, tid);
+        const double total = red[0];
+        __syncthreads();
+        return total;
+    };
+    double cost = cost_of(sR, st);
+    for(int it = 0; it < 30; ++it)
+    {
+        double acc[27]; // upper triangle of J^T J (21) and J^T r (6)
+        for(int j = 0; j < 27; ++j)
+            acc[j] = 0.0;
+        for(int i = tid; i < n; i += kPnpThreads)
+            if(a.mask[i])
+            {
+                const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
+                const V3 Y = mulR(sR, P); // rotated, not translated
+                const V3 X = Y + v3(st[0], st[1], st[2]);
+                if(!(X.z > 1e-9))
+                    continue;
+                const double iz = 1.0 / X.z;
+                const double ru = cam.fx * X.x * iz + cam.cx - (double)a.img[2 * i];
+                const double rv = cam.fy * X.y * iz + cam.cy - (double)a.img[2 * i + 1];
+                // d(u, v)/dX, dX/dw = -[Y]x, dX/dt = I
+                const double ux = cam.fx * iz, uz = -cam.fx * X.x * iz * iz, vy = cam.fy * iz, vz = -cam.fy * X.y * iz * iz;
+                const double Ju[6] = {uz * Y.y, ux * Y.z - uz * Y.x, -ux * Y.y, ux, 0.0, uz};
+                const double Jv[6] = {-vy * Y.z + vz * Y.y, -vz * Y.x, vy * Y.x, 0.0, vy, vz};
+                int k = 0;
+                for(int r = 0; r < 6; ++r)
+                    for(int c2 = r; c2 < 6; ++c2)
+                        acc[k++] += Ju[r] * Ju[c2] + Jv[r] * Jv[c2];
+                for(int r = 0; r < 6; ++r)
+                    acc[21 + r] += Ju[r] * ru + Jv[r] * rv;
+            }
+        wg_sum(acc, 27, red, tid);
+        if(tid == 0)
+        {
+            double H[36], g[6];
+            int k = 0;
+            for(int r = 0; r < 6; ++r)
+                for(int c2 = r; c2 < 6; ++c2)
+                    H[r * 6 + c2] = H[c2 * 6 + r] = red[(k++) * kPnpThreads];
+            for(int r = 0; r < 6; ++r)
+                g[r] = red[(21 + r) * kPnpThreads];
+            for(int r = 0; r < 6; ++r)
+                H[r * 6 + r] += s_lambda * H[r * 6 + r] + 1e-12;
+            // Cholesky H = L L^T, solve H d = -g
+            double L[36];
+            bool ok = true;
+            for(int r = 0; r < 6 && ok; ++r)
+                for(int c2 = 0; c2 <= r; ++c2)
+                {
+                    double sum = H[r * 6 + c2];
+                    for(int j = 0; j < c2; ++j)
+                        sum -= L[r * 6 + j] * L[c2 * 6 + j];
+                    if(r == c2)
+                    {
+                        if(!(sum > 0.0))
+                        {
+                            ok = false;
+                            break;
+                        }
+                        L[r * 6 + r] = sqrt(sum);
+                    }
+                    else
+                        L[r * 6 + c2] = sum / L[c2 * 6 + c2];
+                }
+            double d[6] = {0, 0, 0, 0, 0, 0};
+            if(ok)
+            {
+                double y[6];
+                for(int r = 0; r < 6; ++r)
+                {
+                    double sum = -g[r];
+                    for(int j = 0; j < r; ++j)
+                        sum -= L[r * 6 + j] * y[j];
+                    y[r] = sum / L[r * 6 + r];
+                }
+                for(int r = 5; r >= 0; --r)
+                {
+                    double sum = y[r];
+                    for(int j = r + 1; j < 6; ++j)
+                        sum -= L[j * 6 + r] * d[j];
+                    d[r] = sum / L[r * 6 + r];
+                }
+            }
+            // R' = exp(w) R (Rodrigues), t' = t + dt
+            const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const double th = sqrt(th2);
+            double A, B; // sin(th)/th, (1 - cos(th))/th^2
+            if(th < 1e-4)
+                A = 1.0 - th2 / 6.0, B = 0.5 - th2 / 24.0;
+            else
+            {
+                double sn, cs;
+                mslam_sincos_f64(th, &sn, &cs);
+                A = sn / th, B = (1.0 - cs) / th2;
+            }
+            const double wx = d[0], wy = d[1], wz = d[2];
+            const double E[9] = {1.0 - B * (wy * wy + wz * wz), -A * wz + B * wx * wy, A * wy + B * wx * wz,
+                                 A * wz + B * wx * wy, 1.0 - B * (wx * wx + wz * wz), -A * wx + B * wy * wz,
+                                 -A * wy + B * wx * wz, A * wx + B * wy * wz, 1.0 - B * (wx * wx + wy * wy)};
+            for(int r = 0; r < 3; ++r)
+                for(int c2 = 0; c2 < 3; ++c2)
+                    sNew[r * 3 + c2] = E[r * 3] * sR[c2] + E[r * 3 + 1] * sR[3 + c2] + E[r * 3 + 2] * sR[6 + c2];
+            sNew[9] = st[0] + d[3], sNew[10] = st[1] + d[4], sNew[11] = st[2] + d[5];
+            s_cost = sqrt(th2 + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]); // step length
+        }
+        __syncthreads();
+        const double step = s_cost;
+        const double trial = cost_of(sNew, sNew + 9);
+        if(tid == 0)
+        {
+            if(trial < cost)
+            {
+                for(int j = 0; j < 9; ++j)
+                    sR[j] = sNew[j];
+                st[0] = sNew[9], st[1] = sNew[10], st[2] = sNew[11];
+                s_lambda = fmax(s_lambda * 0.1, 1e-12);
+                s_stop = (step < 1e-12 || cost - trial <= 1e-14 * cost) ? 1 : 0;
+            }
+            else
+            {
+                s_lambda *= 10.0;
+                s_stop = s_lambda > 1e12 ? 1 : 0;
+            }
+        }
+        if(trial < cost)
+            cost = trial;
+        __syncthreads();
+        if(s_stop)
+            break;
+    }
+    if(tid == 0)
+    {
+        for(int j = 0; j < 9; ++j)
+            a.out[j] = sR[j];
+        a.out[9] = st[0], a.out[10] = st[1], a.out[11] = st[2];
+        a.out[12] = (double)s_cnt;
+        a.out[13] = (double)best;
+        a.out[14] = 1.0;
+        a.out[15] = cost;
+    }
+}
+
+} // namespace mslam
+
+using namespace mslam;
+
+static void rodrigues_to_R(const double r[3], double R[9])
+{
+    const double th = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if(th < 1e-12)
+    {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for(int i = 0; i < 9; ++i)
+            R[i] = I[i];
+        return;
+    }
+    const double kx = r[0] / th, ky = r[1] / th, kz = r[2] / th, c = std::cos(th), s = std::sin(th), v = 1 - c;
+    R[0] = c + kx * kx * v, R[1] = kx * ky * v - kz * s, R[2] = kx * kz * v + ky * s;
+    R[3] = ky * kx * v + kz * s, R[4] = c + ky * ky * v, R[5] = ky * kz * v - kx * s;
+    R[6] = kz * kx * v - ky * s, R[7] = kz * ky * v + kx * s, R[8] = c + kz * kz * v;
+}
+
+static void R_to_rodrigues(const double R[9], double r[3])
+{
+    const double tr = R[0] + R[4] + R[8];
+    double c = 0.5 * (tr - 1.0);
+    c = c > 1 ? 1 : c < -1 ? -1 : c;
+    const double th = std::acos(c);
+    const double ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1];
+    const double s2 = std::sqrt(ax * ax + ay * ay + az * az); // 2 sin(th)
+    if(s2 > 1e-9)
+    {
+        r[0] = th * ax / s2, r[1] = th * ay / s2, r[2] = th * az / s2;
+        return;
+    }
+    if(c > 0)
+    {
+        r[0] = 0.5 * ax, r[1] = 0.5 * ay, r[2] = 0.5 * az; // small angle
+        return;
+    }
+    // angle near pi: axis from the diagonal
+    double k[3] = {std::sqrt(std::fmax(0.0, 0.5 * (R[0] + 1))), std::sqrt(std::fmax(0.0, 0.5 * (R[4] + 1))),
+                   std::sqrt(std::fmax(0.0, 0.5 * (R[8] + 1)))};
+    if(R[1] + R[3] < 0)
+        k[1] = -k[1];
+    if(R[2] + R[6] < 0)
+        k[2] = -k[2];
+    r[0] = th * k[0], r[1] = th * k[1], r[2] = th * k[2];
+}
+
+extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points, const float* image_points, int n, double fx,
+                                    double fy, double cx, double cy, int use_extrinsic_guess, int iterations,
+                                    double reprojection_error, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers,
+                                    int* n_inliers)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    auto fail = [&](int code, const char* msg) {
+        c->err = msg;
+        return code;
+    };
+    if(!object_points || !image_points || !rvec || !tvec || n < 4 || iterations < 1 || iterations > 4096 ||
+       !(reprojection_error > 0) || !(fx != 0.0) || !(fy != 0.0))
+        return fail(MSLAM_HIP_E_INVALID, "pnp_ransac: bad argument (at least 4 points, 1..4096 iterations)");
+    if(n_inliers)
+        *n_inliers = 0;
+    hipError_t e = hipSetDevice(c->p.device);
+    float *d_obj = nullptr, *d_img = nullptr;
+    double *d_hyp = nullptr, *d_out = nullptr;
+    int32_t* d_counts = nullptr;
+    uint8_t* d_mask = nullptr;
+    auto cleanup = [&]() {
+        void* bufs[] = {d_obj, d_img, d_hyp, d_out, d_counts, d_mask};
+        for(void* b : bufs)
+            if(b)
+                (void)hipFree(b);
+    };
+#define PCHK(call)                                                                                                     \
+    if(e == hipSuccess)                                                                                                \
+    e = (call)
+    PCHK(hipMalloc(reinterpret_cast<void**>(&d_obj), (size_t)n * 12));
+    PCHK(hipMalloc(reinterpret_cast<void**>(&d_img), (size_t)n * 8));
+    PCHK(hipMalloc(reinterpret_cast<void**>(&d_hyp), (size_t)iterations * 12 * 8));
+    PCHK(hipMalloc(reinterpret_cast<void**>(&d_out), 16 * 8));
+    PCHK(hipMalloc(reinterpret_cast<void**>(&d_counts), (size_t)iterations * 4));
+    PCHK(hipMalloc(reinterpret_cast<void**>(&d_mask), (size_t)n));
+    PCHK(hipMemcpyAsync(d_obj, object_points, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    PCHK(hipMemcpyAsync(d_img, image_points, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    PnpArgs a{};
+    a.obj = d_obj, a.img = d_img, a.n = n;
+    a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
+    a.use_guess = use_extrinsic_guess ? 1 : 0;
+    rodrigues_to_R(rvec, a.R0);
+    a.t0[0] = tvec[0], a.t0[1] = tvec[1], a.t0[2] = tvec[2];
+    a.iterations = iterations;
+    a.thr2 = reprojection_error * reprojection_error;
+    a.seed = seed;
+    a.hyp = d_hyp, a.counts = d_counts, a.mask = d_mask, a.out = d_out;
+    const size_t lds = (size_t)28 * kPnpThreads * 8;
+    PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if(e == hipSuccess)
+        hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(kPnpThreads), lds, c->stream, a);
+    PCHK(hipGetLastError());
+    double out[16] = {0};
+    std::vector<uint8_t> mask((size_t)n);
+    PCHK(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    PCHK(hipMemcpyAsync(mask.data(), d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    PCHK(hipStreamSynchronize(c->stream));
+#undef PCHK
+    cleanup();
+    if(e != hipSuccess)
+    {
+        c->err = std::string("pnp_ransac: ") + hipGetErrorString(e);
+        return MSLAM_HIP_E_RUNTIME;
+    }
+    if(out[14] != 1.0)
+        return fail(MSLAM_HIP_E_NO_MODEL, "pnp_ransac: no hypothesis reached 4 inliers");
+    R_to_rodrigues(out, rvec);
+    tvec[0] = out[9], tvec[1] = out[10], tvec[2] = out[11];
+    if(inliers)
+        std::memcpy(inliers, mask.data(), (size_t)n);
+    if(n_inliers)
+        *n_inliers = (int)out[12];
+    return MSLAM_HIP_OK;
+}

@@ -1,0 +1,87 @@
+"""RANSAC PnP (row f-3; reference call site cv_ransac_pnp.cpp:56-57).  CPU: the numpy oracle recovers ground-truth poses.
+GPU: the HIP solver against ground truth and against the oracle (same samples by construction: same splitmix64 rule)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mslam_pnp_oracle as po  # noqa: E402
+
+CAM = (525.0, 525.0, 319.5, 239.5)      # TUM intrinsics, rgbd_file_provider.cpp:136-145
+
+
+def scene(seed, n=400, outliers=0.3, noise=0.5):
+    rng = np.random.default_rng(seed)
+    R = po.rodrigues(rng.normal(size=3) * 0.4)
+    t = rng.normal(size=3) * 0.3 + np.array([0.1, -0.2, 0.5])
+    obj = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2, 7, n)], 1)
+    obj = ((obj - t) @ R).astype(np.float32)            # world points whose camera coordinates are the box above
+    img, ok = po.project(R, t, obj.astype(np.float64), CAM)
+    assert ok.all()
+    img += rng.normal(size=img.shape) * noise
+    bad = rng.random(n) < outliers
+    img[bad] = rng.uniform(0, [640, 480], (int(bad.sum()), 2))
+    return obj, img.astype(np.float32), R, t, ~bad
+
+
+def rot_err(Ra, Rb):
+    return np.degrees(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+
+
+def test_oracle_recovers_ground_truth():
+    for seed in range(4):
+        obj, img, R, t, good = scene(seed)
+        res = po.pnp_ransac(obj, img, CAM, seed=seed)
+        assert res is not None and rot_err(res["R"], R) < 0.1 and np.linalg.norm(res["t"] - t) < 0.02
+        assert (res["mask"] & ~good).sum() <= 5 and res["mask"].sum() > 0.9 * good.sum()
+    # the extrinsic guess is the refinement's starting point (useExtrinsicGuess = true): a nearby guess converges to the
+    # same optimum
+    obj, img, R, t, good = scene(7)
+    res = po.pnp_ransac(obj, img, CAM, seed=1, guess=(po.rodrigues([0.02, -0.01, 0.03]) @ R, t + 0.05))
+    assert rot_err(res["R"], R) < 0.1 and np.linalg.norm(res["t"] - t) < 0.02
+    # no consensus: pure garbage yields no model
+    rng = np.random.default_rng(5)
+    assert po.pnp_ransac(rng.normal(size=(50, 3)).astype(np.float32) + [0, 0, 5],
+                         rng.uniform(0, 480, (50, 2)).astype(np.float32), CAM, thr=0.5) is None
+
+
+def test_p3p_solutions_contain_the_true_pose():
+    rng = np.random.default_rng(11)
+    for _ in range(50):
+        obj, img, R, t, _ = scene(int(rng.integers(1 << 30)), n=8, outliers=0.0, noise=0.0)
+        sols = po.p3p(obj[:3].astype(np.float64), img[:3].astype(np.float64), CAM)
+        assert any(rot_err(Rs, R) < 1e-3 and np.linalg.norm(ts - t) < 1e-4 for Rs, ts in sols)
+
+
+@pytest.mark.gpu
+def test_gpu_pnp_matches_ground_truth_and_oracle(pkg):
+    c = pkg.Context(width=0, height=0)
+    for seed in range(6):
+        obj, img, R, t, good = scene(seed, n=300 + 200 * seed, outliers=0.1 * (seed % 4), noise=0.4)
+        got = c.pnp_ransac(obj, img, CAM[:2], CAM[2:], seed=seed)
+        assert got is not None
+        r, tv, mask = got
+        Rg = po.rodrigues(r)
+        assert rot_err(Rg, R) < 0.1 and np.linalg.norm(tv - t) < 0.02                 # ground truth
+        ref = po.pnp_ransac(obj, img, CAM, seed=seed)
+        assert np.array_equal(mask, ref["mask"]), (seed, mask.sum(), ref["mask"].sum())   # same best hypothesis
+        assert rot_err(Rg, ref["R"]) < 1e-6 and np.linalg.norm(tv - ref["t"]) < 1e-7   # same optimum
+    # with an extrinsic guess (what the reference passes, cv_ransac_pnp.cpp:56): same optimum from a nearby start
+    obj, img, R, t, good = scene(9)
+    R0 = po.rodrigues([0.02, -0.01, 0.03]) @ R
+    th = np.arccos((np.trace(R0) - 1) / 2)
+    r0 = th / (2 * np.sin(th)) * np.array([R0[2, 1] - R0[1, 2], R0[0, 2] - R0[2, 0], R0[1, 0] - R0[0, 1]])
+    r, tv, mask = c.pnp_ransac(obj, img, CAM[:2], CAM[2:], rvec=r0, tvec=t + 0.05, seed=3)
+    ref = po.pnp_ransac(obj, img, CAM, seed=3, guess=(R0, t + 0.05))
+    assert np.array_equal(mask, ref["mask"]) and rot_err(po.rodrigues(r), ref["R"]) < 1e-6
+    assert np.linalg.norm(tv - ref["t"]) < 1e-7 and rot_err(po.rodrigues(r), R) < 0.1
+    # no model
+    rng = np.random.default_rng(5)
+    assert c.pnp_ransac(rng.normal(size=(50, 3)).astype(np.float32) + [0, 0, 5],
+                        rng.uniform(0, 480, (50, 2)).astype(np.float32), CAM[:2], CAM[2:], reprojection_error=0.5) is None
+    with pytest.raises(pkg.MslamHipError):
+        c.pnp_ransac(obj[:3], img[:3], CAM[:2], CAM[2:])
+    c.close()
