@@ -40,9 +40,15 @@ __device__ __forceinline__ uint32_t dot2u(uint32_t pair, uint32_t taps, uint32_t
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, Geometry g,
-                                              Taps taps)
+                                              Taps taps, int n_frames, int blocks_per_frame)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware mapping (as k_fast_cells): the strips of one frame share rows (3-row halos) and 128-byte lines, so all
+    // workgroups of a frame get ids with the same (id & 7) and meet in one L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int f_local = (slot / blocks_per_frame) * 8 + xcd;
+    if(f_local >= n_frames)
+        return;
+    const int idx = (slot % blocks_per_frame) * 256 + threadIdx.x;
     if(idx >= g.n_tiles)
         return;
     int level = 0;
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const int x0 = (sidx - band * lv.bsx) * 4;
     const int y0 = band * kBlurRows;
     const int w = lv.w, h = lv.h, pitch = lv.pitch;
-    const size_t frame = blockIdx.y + g.frame0;
+    const size_t frame = (size_t)f_local + g.frame0;
     // wave-uniform frame bases + 32-bit per-lane offsets (the level differs between lanes): loads and stores take the
     // SGPR-base + VGPR-offset form and no 64-bit address arithmetic is needed per row
     const uint8_t* src = pyr + frame * g.slab;
@@ -166,10 +172,11 @@ void set_blur_taps(const int* t)
 
 void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int frame0, int n_frames, hipStream_t s)
 {
-    dim3 grid((g.n_tiles + 255) / 256, n_frames);
+    const int bpf = (g.n_tiles + 255) / 256;
+    const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)bpf;
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, d_pyr, d_blur, gg, g_taps);
+    hipLaunchKernelGGL(k_blur, dim3(grid), dim3(256), 0, s, d_pyr, d_blur, gg, g_taps, n_frames, bpf);
 }
 
 } // namespace mslam

@@ -61,7 +61,7 @@ __device__ __forceinline__ int arc_score(const int (&d)[16])
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, Geometry g,
                                                     const CellDesc* __restrict__ cells, uint32_t* __restrict__ cell_cnt,
-                                                    uint32_t* __restrict__ cell_kp, int ini_thr, int min_thr)
+                                                    uint32_t* __restrict__ cell_kp, int ini_thr, int min_thr, int n_frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kScP];
@@ -70,8 +70,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     __shared__ uint32_t bitmap[64 * 2];
     __shared__ uint32_t n_cand;
 
-    const int cell_id = blockIdx.x;
-    const size_t frame = blockIdx.y + g.frame0;
+    // XCD-aware mapping: workgroups are handed to the 8 XCDs round-robin by linear id, and neighbouring cells share
+    // 128-byte lines (a 70-byte cell row straddles two of them, its neighbours use the rest).  With cells of one
+    // frame spread over all XCDs every L2 fetched those lines again — 2.7x the level's bytes at the memory side
+    // (profiles/r02_a_pmc_fetch_write_per_launch.json); all cells of a frame now get ids with the same (id & 7).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int f_local = (slot / g.n_cells) * 8 + xcd;
+    if(f_local >= n_frames)
+        return;
+    const int cell_id = slot % g.n_cells;
+    const size_t frame = (size_t)f_local + g.frame0;
     const CellDesc c = cells[cell_id];
     const LevelGeom& lv = g.lv[c.level];
     const int cw = c.cw, ch = c.ch;
@@ -282,10 +290,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
                  uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s)
 {
-    dim3 grid(g.n_cells, n_frames);
+    const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)g.n_cells;
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, d_pyr, gg, d_cells, d_cell_cnt, d_cell_kp, ini_thr, min_thr);
+    hipLaunchKernelGGL(k_fast_cells, dim3(grid), dim3(256), 0, s, d_pyr, gg, d_cells, d_cell_cnt, d_cell_kp, ini_thr, min_thr,
+                       n_frames);
 }
 
 } // namespace mslam
