@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Diffs a dump written by opencv_dump (real OpenCV) against the oracle's restatements, primitive by primitive.
+usage: compare.py dump.bin frame0.bgr frame1.bgr width height      (run from the repository root)
+Prints one PASS / FAIL line per record; exit code 1 when anything differs.  cv::ORB keypoints are compared as sets per
+octave (the reference's order inside a level is what std::nth_element leaves behind), descriptors after matching
+keypoints by (octave, x, y); a descriptor may differ where the host libm's cosf/sinf differs from
+include/mslam_sincos.h (reported separately)."""
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+
+def load(path):
+    out, b, p = {}, open(path, "rb").read(), 0
+    while p < len(b):
+        n, = struct.unpack_from("<I", b, p)
+        name = b[p + 4:p + 4 + n].decode()
+        p += 4 + n
+        dt, nd = struct.unpack_from("<II", b, p)
+        dims = struct.unpack_from("<%dI" % nd, b, p + 8)
+        p += 8 + 4 * nd
+        dtype = (np.uint8, np.int32, np.float32)[dt]
+        cnt = int(np.prod(dims)) if nd else 1
+        out[name] = np.frombuffer(b, dtype, cnt, p).reshape(dims)
+        p += cnt * np.dtype(dtype).itemsize
+    return out
+
+
+def main():
+    dump, W, H = load(sys.argv[1]), int(sys.argv[4]), int(sys.argv[5])
+    orc = graft.load_oracle()
+    orc.lib()
+    bad = 0
+
+    def check(name, ok, note=""):
+        nonlocal bad
+        bad += 0 if ok else 1
+        print("%-4s %s %s" % ("PASS" if ok else "FAIL", name, note))
+    for f in range(2):
+        F = "f%d_" % f
+        bgr = np.fromfile(sys.argv[2 + f], np.uint8).reshape(H, W, 3)
+        gray = orc.gray(bgr)
+        check(F + "gray", np.array_equal(gray, dump[F + "gray"]))
+        p = orc.params()
+        pyr = orc.pyramid(gray, p)
+        for l in range(1, 8):
+            check(F + "linear_L%d" % l, np.array_equal(pyr[l], dump[F + "linear_L%d" % l]))
+        cp = orc.cvorb_params()
+        epyr = orc.cvorb_pyramid(gray, cp)
+        for l in range(1, 8):
+            check(F + "exact_L%d" % l, np.array_equal(epyr[l], dump[F + "exact_L%d" % l]))
+        for l in (0, 3, 6):
+            check(F + "blur_L%d" % l, np.array_equal(orc.gaussian_blur7(pyr[l]), dump[F + "blur_L%d" % l]))
+            k = orc.fast(pyr[l], 20, cap=pyr[l].size // 4)
+            ref = dump[F + "fast20_L%d" % l]
+            check(F + "fast20_L%d" % l, len(k) == len(ref) and np.array_equal(
+                np.stack([k["x"], k["y"], k["response"]], 1), ref[:, :3]))
+        for i in range(2):
+            for j in range(9):
+                for thr in (20, 7):
+                    name = F + "cell_%d_%d_t%d" % (i, j, thr)
+                    k = orc.fast(gray[19 + 64 * i:19 + 64 * i + 70, 19 + 64 * j:19 + 64 * j + 70], thr)
+                    ref = dump[name]
+                    check(name, len(k) == len(ref) and np.array_equal(np.stack([k["x"], k["y"], k["response"]], 1), ref[:, :3]))
+        d = orc.cvorb_detect(bgr, cp)
+        ref, rdesc = dump[F + "orb_keypoints"], dump[F + "orb_descriptors"]
+        mine = {(int(o), float(x), float(y)): i for i, ((x, y), o) in enumerate(zip(d["xy"], d["octave"]))}
+        theirs = {(int(r[4]), float(r[0]), float(r[1])): i for i, r in enumerate(ref)}
+        check(F + "orb keypoint set", set(mine) == set(theirs), "%d vs %d" % (len(mine), len(theirs)))
+        common = sorted(set(mine) & set(theirs))
+        ang = sum(d["angle"][mine[k]] == ref[theirs[k], 3] for k in common)
+        resp = sum(d["response"][mine[k]] == ref[theirs[k], 2] for k in common)
+        dd = sum(np.array_equal(d["desc"][mine[k]], rdesc[theirs[k]]) for k in common)
+        check(F + "orb angles", ang == len(common), "%d / %d" % (ang, len(common)))
+        check(F + "orb harris responses", resp == len(common), "%d / %d" % (resp, len(common)))
+        check(F + "orb descriptors", dd == len(common), "%d / %d equal (differences may stem from libm cosf/sinf)" % (dd, len(common)))
+    a = np.array([[orc.fast_atan2(float(y * 977), float(x * 1013)) for x in range(-40, 41)] for y in range(-40, 41)], np.float32)
+    check("fast_atan2", np.array_equal(a, dump["fast_atan2"]))
+    i0, i1, d0, d1 = orc.match_knn2_raw(dump["f1_orb_descriptors"], dump["f0_orb_descriptors"])
+    check("knn2", np.array_equal(np.stack([i0, d0, i1, d1], 1), dump["knn2"]))
+    print("%d record(s) differ" % bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
