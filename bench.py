@@ -117,6 +117,10 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=8)
     ap.add_argument("--min-area", type=int, default=1000, help="quadtree stop area (reference default 1000)")
+    ap.add_argument("--detector", default="distributed", choices=["distributed", "cvorb"],
+                    help="distributed = DistributedOrbOpenCvDetector (the headline); cvorb = the cv::ORB-based "
+                         "OrbOpenCvDetector drop-in (n_features keypoints per frame)")
+    ap.add_argument("--n-features", type=int, default=1000, help="cvorb: cv::ORB::create(nfeatures)")
     ap.add_argument("--bow", action="store_true",
                     help="cfg3/cfg4: DBoW3 loop scoring every frame (synthetic k=10 vocabulary) inside the step and, "
                          "with N>1, the RCCL all-gather of BoW vectors + cross-stream scoring")
@@ -165,7 +169,7 @@ def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
     }
 
 
-def cpu_baseline(frames, params_kw, seconds):
+def cpu_baseline(frames, params_kw, seconds, cv=False, n_features=1000):
     """Oracle (= port of the reference CPU plugin) detect + match on the host cores: one core, then all cores
     (frames sharded over threads; the C oracle releases the GIL inside ctypes calls)."""
     import __graft_entry__ as graft
@@ -173,20 +177,25 @@ def cpu_baseline(frames, params_kw, seconds):
     orc = graft.load_oracle()
     orc.lib()
     cores = os.cpu_count() or 1
-    p = orc.params(**params_kw)
+    if cv:
+        p = orc.cvorb_params(n_features=n_features, n_levels=params_kw["n_levels"])
+        detect = orc.cvorb_detect
+    else:
+        p = orc.params(**params_kw)
+        detect = orc.detect
 
     def run(n, threads):
         sample = [np.ascontiguousarray(frames[i % len(frames)]) for i in range(n)]
         t0 = time.perf_counter()
         with ThreadPoolExecutor(threads) as ex:
-            dets = list(ex.map(lambda i: orc.detect(sample[i], p), range(n)))
+            dets = list(ex.map(lambda i: detect(sample[i], p), range(n)))
             list(ex.map(lambda i: orc.match(dets[i]["desc"], dets[i - 1]["desc"]), range(1, n)))
         dt = time.perf_counter() - t0
         return sum(len(d["xy"]) for d in dets) / dt, dt
 
     # size the samples from a short probe so that the leg stays within its budget on any host
     t0 = time.perf_counter()
-    d0 = orc.detect(np.ascontiguousarray(frames[0]), p)
+    d0 = detect(np.ascontiguousarray(frames[0]), p)
     orc.match(d0["desc"], d0["desc"])
     per_frame = max(time.perf_counter() - t0, 1e-3)
     n1 = int(max(4, min(len(frames), 0.3 * seconds / per_frame)))
@@ -268,8 +277,13 @@ def main():
     area = max(1, -(-a.width * a.height // (640 * 480)))
     k_scale = area * max(1, 1000 // max(a.min_area, 1))
     ts = torch.cuda.Stream()  # the context's stream is a torch stream: torch copies / collectives order against it
+    cv = a.detector == "cvorb"
+    if cv:
+        STAGE_KERNEL.update({"resize": "mslam::k_resize_exact", "fast": "mslam::k_fast_score", "select": "mslam::k_cv_select"})
     ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=a.min_area,
-                      max_keypoints=min(65535, 4096 * k_scale), max_candidates=16384 * area, device=dev, stream=ts.cuda_stream)
+                      max_keypoints=min(32736, max(4096 * k_scale, 2 * a.n_features if cv else 0)),  # 32736: the matrix-core matcher's train range
+                      max_candidates=16384 * area, device=dev, stream=ts.cuda_stream,
+                      detector=pkg.DETECTOR_CV_ORB if cv else pkg.DETECTOR_DISTRIBUTED, n_features=a.n_features)
     n_batches = n_unique // B
     cross = None
     need_voc = a.bow or (world > 1 and not a.no_extras)
@@ -473,7 +487,9 @@ def main():
         acc = {k: tot[k] / steps_cov for k in tot}                   # ms per step, summed over the step's launches
         kp_b, cand_b = counts_per_batch[0], cand_per_batch[0]
         sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)   # per step (B frames)
-        dom = max(acc, key=acc.get)
+        if cv:  # the selection stage of the cv::ORB mode stands where the quadtree is (same order of bytes)
+            sb["select"] = sb["quadtree"]
+        dom = max((k for k in acc if k in sb), key=acc.get)
         fpl = B / per_step[dom]                                    # frames per launch of the dominant stage
         bytes_per_launch = sb[dom] / per_step[dom]
         achieved = bytes_per_launch / (avg[dom] * 1e-3) / 1e9
@@ -521,7 +537,8 @@ def main():
             "bytes_per_frame": int(extract_bytes), "achieved_GBps_per_gpu": round(extract_gbs / world, 1),
             "frac": round(extract_gbs / world / HBM_PEAK_GBS, 4),
             "what": "SURVEY.md §8d whole-extract figure 3WH + 2P + 48K per frame x frames/s of the whole step"}
-        cfg = "cfg2" if (a.width, a.height, a.levels) == (640, 480, 8) else "%dx%d, %d levels" % (a.width, a.height, a.levels)
+        cfg = "cfg2" if (a.width, a.height, a.levels, cv) == (640, 480, 8, False) else "%dx%d, %d levels%s" % (
+            a.width, a.height, a.levels, ", cv::ORB detector mode (n_features %d)" % a.n_features if cv else "")
         out = {
             "metric": baseline_metric(), "value": kp_total / dt_max,
             "unit": "keypoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -548,7 +565,8 @@ def main():
             extras["popcount_match_kernel"] = POPCOUNT_KERNEL
         out.update(extras)
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, dict(n_levels=a.levels, min_size=a.min_area), a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(frames, dict(n_levels=a.levels, min_size=a.min_area), a.cpu_seconds, cv,
+                                               a.n_features)
     ctx.close()
     if world > 1:
         dist.barrier()

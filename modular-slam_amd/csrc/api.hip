@@ -324,12 +324,15 @@ static void exact_axis(int ssize, int dsize, std::vector<int32_t>& ofs, std::vec
             }
             else
             {
-                o = ssize - 1;
+                // right of the range: the last sample (hlineResizeCn), stored as offset ssize-2 with weights 0 / 256 so that
+                // the kernel's unconditional second read stays inside the row
+                o = ssize - 2;
+                c0 = 0, c1 = 256;
                 dmax = std::min(dmax, d);
             }
         }
         else
-            dmin = std::max(dmin, d + 1);
+            dmin = std::max(dmin, d + 1); // left of the range: the first sample = offset 0, weights 256 / 0 (the defaults)
         ofs.push_back(o);
         coef.push_back(c0 | (c1 << 16));
     }
@@ -496,12 +499,28 @@ static int create_impl(mslam_hip_ctx* c)
         c->cv_x.assign(p.n_levels, 0);
         c->cv_y.assign(p.n_levels, 0);
         c->cv_range.assign(p.n_levels, std::array<int, 4>{0, 0, 0, 0});
+        c->cv_window12.assign(p.n_levels, 0);
         for(int l = 1; l < p.n_levels; ++l)
         {
             c->cv_x[l] = ofs.size();
             exact_axis(g.lv[l - 1].w, g.lv[l].w, ofs, coef, c->cv_range[l][0], c->cv_range[l][1]);
             c->cv_y[l] = ofs.size();
             exact_axis(g.lv[l - 1].h, g.lv[l].h, ofs, coef, c->cv_range[l][2], c->cv_range[l][3]);
+            // the window form needs, for every destination quad, o3 + 1 - (o0 & ~3) <= 11, the window inside the pitch and
+            // the kernel's unconditional "next row" read inside the level
+            bool ok = true;
+            const int dw = g.lv[l].w;
+            for(int q = 0; q * 4 < dw && ok; ++q)
+            {
+                const int base = ofs[c->cv_x[l] + 4 * q] & ~3;
+                for(int k = 0; k < 4; ++k)
+                {
+                    const int o = ofs[c->cv_x[l] + std::min(4 * q + k, dw - 1)];
+                    ok = ok && o >= base && o + 1 - base <= 11;
+                }
+                ok = ok && base + 12 <= g.lv[l - 1].pitch;
+            }
+            c->cv_window12[l] = ok ? 1 : 0;
         }
         ofs.push_back(0);
         coef.push_back(0);
@@ -753,6 +772,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                     ra.ycoef = c->d_cv_coef + c->cv_y[l];
                     ra.xmin = c->cv_range[l][0], ra.xmax = c->cv_range[l][1];
                     ra.ymin = c->cv_range[l][2], ra.ymax = c->cv_range[l][3];
+                    ra.window12 = c->cv_window12[l];
                     ra.frame0 = f0;
                     launch_resize_exact(ra, nf, cs);
                 }
@@ -767,14 +787,15 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             for(int l = 0; l < g.n_levels; ++l)
                 sa.quota[l] = c->cv_quota[l];
             {
-                // the FAST score plane lives in the blur slab until the blur (which comes last) overwrites it
                 StageScope t(c, "fast", cs);
+                // the tiles of a level append to its list with atomics: counts start at zero
+                HIPCHK(c, hipMemsetAsync(c->quad.cand_cnt + (size_t)f0 * g.n_levels, 0, (size_t)nf * g.n_levels * 4, cs));
                 for(int l = 0; l < g.n_levels; ++l)
-                    launch_fast_score(c->d_pyr, c->d_blur, g, l, c->p.ini_fast_thr, f0, nf, cs);
+                    launch_fast_tiles(c->d_pyr, g, l, c->p.ini_fast_thr, sa, f0, nf, cs);
             }
             {
                 StageScope t(c, "select", cs);
-                launch_cv_select(c->d_pyr, c->d_blur, g, sa, f0, nf, cs);
+                launch_cv_select(c->d_pyr, g, sa, f0, nf, cs);
             }
         }
         else
@@ -1304,6 +1325,7 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
         const bool cand = what == MSLAM_HIP_DBG_CANDIDATES;
         uint32_t n = 0;
         HIPCHK(c, hipMemcpy(&n, (cand ? c->quad.cand_cnt : c->quad.sel_cnt) + slot, 4, hipMemcpyDeviceToHost));
+        n = std::min<uint32_t>(n, (uint32_t)c->p.max_candidates); // an overflowing level keeps counting (flagged separately)
         *n_items = n;
         if(dst_bytes < (size_t)n * 12)
             return fail(c, MSLAM_HIP_E_CAPACITY, "debug_read: buffer too small");

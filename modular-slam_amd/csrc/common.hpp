@@ -147,12 +147,11 @@ struct ExactResizeArgs
     const uint32_t* xcoef; // [dw] c0 | c1 << 16 (8.8 fixed point, c0 + c1 = 256)
     const int32_t* yofs;   // [dh]
     const uint32_t* ycoef; // [dh]
-    int xmin, xmax, ymin, ymax; // destination positions outside [min, max) copy the first / last source sample
+    int xmin, xmax, ymin, ymax; // destination positions outside [min, max) copy the first / last source sample (folded into the tables)
+    int window12;               // 1: the 4 pixels of every destination quad read inside one aligned 12-byte source window
     int frame0;
 };
 void launch_resize_exact(const ExactResizeArgs& a, int n_frames, hipStream_t s);
-void launch_fast_score(const uint8_t* d_pyr, uint8_t* d_plane, const Geometry& g, int level, int thr, int frame0,
-                       int n_frames, hipStream_t s);
 struct CvSelectArgs
 {
     uint32_t* cand;     // [B][L][cand_cap] FAST keypoints after NMS + border filter, raster order, ABSOLUTE coordinates
@@ -167,8 +166,10 @@ struct CvSelectArgs
     int edge;           // edgeThreshold (31)
     int quota[kMaxLevels]; // nfeaturesPerLevel
 };
-void launch_cv_select(const uint8_t* d_pyr, const uint8_t* d_plane, const Geometry& g, const CvSelectArgs& a, int frame0,
-                      int n_frames, hipStream_t s);
+void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int level, int thr, const CvSelectArgs& a, int frame0,
+                       int n_frames, hipStream_t s);
+void launch_cv_select(const uint8_t* d_pyr, const Geometry& g, const CvSelectArgs& a, int frame0, int n_frames,
+                      hipStream_t s);
 
 // knn-2 Hamming match for `n_pairs` independent (from, to) pairs.  Descriptor sets are addressed as
 // base + pair_index * stride; counts come from device arrays (or fixed values when the pointer is null).

@@ -63,6 +63,7 @@ struct mslam_hip_ctx
     uint32_t* d_cv_coef = nullptr;
     std::vector<size_t> cv_x, cv_y;           // per-level start index into d_cv_*
     std::vector<std::array<int, 4>> cv_range; // per level: xmin, xmax, ymin, ymax
+    std::vector<int> cv_window12;             // per level: k_resize_exact may use its 12-byte-window form
     int cv_quota[mslam::kMaxLevels] = {0};
     int32_t* d_ratio_thr = nullptr; // [257]
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights

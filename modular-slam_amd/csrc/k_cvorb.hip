@@ -4,10 +4,11 @@
 // cv::ORB::create(1000)->detectAndCompute (orb_feature.cpp:25,40).  Everything below that call is OpenCV 4.8.1
 // (features2d/src/orb.cpp; not in the reference tree), restated stage by stage:
 //   pyramid      resize(prev, sz, INTER_LINEAR_EXACT), chained          -> k_resize_exact
-//   FAST         FastFeatureDetector(20, nonmax = true) on the WHOLE level -> k_fast_score (score plane, 64x64
-//                tiles staged in LDS) + k_fast_nms (3x3 strict NMS, runByImageBorder(31), raster-order list)
+//   FAST         FastFeatureDetector(20, nonmax = true) on the WHOLE level -> k_fast_tiles (64x64 tiles staged in LDS:
+//                scores incl. a 1-px ring, 3x3 strict NMS, runByImageBorder(31), per-level list)
 //   selection    retainBest(2 n_l) by FAST score, HarrisResponses (7x7 block, k = 0.04), retainBest(n_l) by Harris
-//                                                                       -> k_cv_select (one workgroup per level)
+//                                                                       -> k_cv_select (one workgroup per level; first
+//                puts the list into FAST's raster order)
 //   orientation, blur, rBRIEF: k_blur and k_describe (shared with the in-tree detector; k_describe takes its
 //                cos/sin from include/mslam_sincos.h in this mode and the Harris response as the keypoint response)
 // retainBest keeps the SET {response >= n-th largest} (ties kept); its ORDER in the reference comes from
@@ -20,58 +21,106 @@ namespace mslam
 // ---- INTER_LINEAR_EXACT (imgproc resize.cpp: resize_bitExact, interpolationLinear<uchar>, ufixedpoint16) ------
 // horizontal: h = c0 * S[o] + c1 * S[o+1] in 8.8 (u16, exact); left of xmin / right of xmax: edge sample << 8.
 // vertical  : (h0 * b0 + h1 * b1 + 2^15) >> 16; above ymin / below ymax: (h + 128) >> 8 of the first / last row.
+// The host tables fold the edge rules in: a position left of xmin is (offset 0, coefficients 256 / 0), right of xmax
+// (offset sw-2, 0 / 256) — the same 8.8 value as "edge sample << 8" — and a row above ymin / below ymax likewise, where
+// (h * 256 + 2^15) >> 16 == (h + 128) >> 8.  The kernel is therefore branch-free: 4 pixels per lane, all loads first.
+// The kernel is branch-free: 4 destination pixels and R = 4 destination rows per lane.  The 4 pixels draw on at most
+// 12 consecutive source bytes (scale <= 2), fetched per source row as three aligned dwords; the pair (S[o], S[o+1])
+// of pixel k is cut out with one v_perm_b32 whose selector depends on (o_k - window base) only, i.e. is computed once
+// per lane, as are the horizontal coefficients.
+template <bool WINDOW>
 __global__ __launch_bounds__(256) void k_resize_exact(ExactResizeArgs a)
 {
+    constexpr int R = 4;
     const int qx = blockIdx.x * 64 + threadIdx.x;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    if(dy >= a.dh || (qx << 2) >= a.dw)
+    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * R;
+    if(dy0 >= a.dh || (qx << 2) >= a.dw)
         return;
     const size_t frame = blockIdx.z + a.frame0;
     const uint8_t* src = a.pyr + frame * a.slab + a.src_off;
     uint8_t* dst = a.pyr + frame * a.slab + a.dst_off;
-    const bool two = dy >= a.ymin && dy < a.ymax;
-    const int r0 = dy < a.ymin ? 0 : (dy >= a.ymax ? a.sh - 1 : a.yofs[dy]);
-    const uint32_t yc = a.ycoef[dy];
-    const uint32_t b0 = yc & 0xFFFF, b1 = yc >> 16;
-    const uint8_t* S0 = src + (size_t)r0 * a.spitch;
-    const uint8_t* S1 = S0 + (two ? a.spitch : 0);
-    uint32_t out = 0;
+    int o[4];
+    uint32_t c0[4], c1[4], sel[4];
 #pragma unroll
     for(int k = 0; k < 4; ++k)
     {
         const int dx = min((qx << 2) + k, a.dw - 1);
-        uint32_t h0, h1;
-        if(dx < a.xmin)
-            h0 = (uint32_t)S0[0] << 8, h1 = (uint32_t)S1[0] << 8;
-        else if(dx >= a.xmax)
-            h0 = (uint32_t)S0[a.sw - 1] << 8, h1 = (uint32_t)S1[a.sw - 1] << 8;
+        o[k] = a.xofs[dx];
+        const uint32_t xc = a.xcoef[dx];
+        c0[k] = xc & 0xFFFF, c1[k] = xc >> 16;
+    }
+    const int base = o[0] & ~3;
+#pragma unroll
+    for(int k = 0; k < 4; ++k)
+    {
+        // bytes (s, s+1) of the 12-byte window -> u16 lanes [S[o], 0, S[o+1], 0]: from dwords (0,1) when s <= 6, else (1,2)
+        const uint32_t sft = (uint32_t)(o[k] - base);
+        sel[k] = 0x0c010c00u + (sft > 6 ? sft - 4 : sft) * 0x00010001u;
+    }
+    for(int r = 0; r < R; ++r)
+    {
+        const int dy = dy0 + r;
+        if(dy >= a.dh)
+            break;
+        const int r0 = a.yofs[dy];
+        const uint32_t yc = a.ycoef[dy];
+        const uint32_t b0 = yc & 0xFFFF, b1 = yc >> 16;
+        const uint8_t* S0 = src + (size_t)r0 * a.spitch;
+        const uint8_t* S1 = S0 + a.spitch;
+        uint32_t h0[4], h1[4];
+        if(WINDOW)
+        {
+            const uint32_t* W0 = reinterpret_cast<const uint32_t*>(S0 + base);
+            const uint32_t* W1 = reinterpret_cast<const uint32_t*>(S1 + base);
+            const uint32_t a0 = W0[0], a1 = W0[1], a2 = W0[2], e0 = W1[0], e1 = W1[1], e2 = W1[2];
+#pragma unroll
+            for(int k = 0; k < 4; ++k)
+            {
+                const bool up = (uint32_t)(o[k] - base) > 6;
+                const uint32_t pa = __builtin_amdgcn_perm(up ? a2 : a1, up ? a1 : a0, sel[k]); // S0[o] | S0[o+1] << 16
+                const uint32_t pe = __builtin_amdgcn_perm(up ? e2 : e1, up ? e1 : e0, sel[k]);
+                // every factor is below 2^16 and every product below 2^24: full-rate 24-bit multiplies
+                h0[k] = __umul24(c0[k], pa & 0xFFFF) + __umul24(c1[k], pa >> 16);
+                h1[k] = __umul24(c0[k], pe & 0xFFFF) + __umul24(c1[k], pe >> 16);
+            }
+        }
         else
         {
-            const int o = a.xofs[dx];
-            const uint32_t xc = a.xcoef[dx];
-            const uint32_t c0 = xc & 0xFFFF, c1 = xc >> 16;
-            h0 = c0 * S0[o] + c1 * S0[o + 1];
-            h1 = c0 * S1[o] + c1 * S1[o + 1];
+#pragma unroll
+            for(int k = 0; k < 4; ++k)
+            {
+                h0[k] = __umul24(c0[k], S0[o[k]]) + __umul24(c1[k], S0[o[k] + 1]);
+                h1[k] = __umul24(c0[k], S1[o[k]]) + __umul24(c1[k], S1[o[k] + 1]);
+            }
         }
-        const uint32_t v = two ? (h0 * b0 + h1 * b1 + 32768u) >> 16 : (h0 + 128u) >> 8;
-        out |= (v & 0xFFu) << (8 * k);
+        uint32_t out = 0;
+#pragma unroll
+        for(int k = 0; k < 4; ++k)
+            out |= (((__umul24(h0[k], b0) + __umul24(h1[k], b1) + 32768u) >> 16) & 0xFFu) << (8 * k);
+        *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch + (qx << 2)) = out;
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch + (qx << 2)) = out;
 }
 
 void launch_resize_exact(const ExactResizeArgs& a, int n_frames, hipStream_t s)
 {
-    dim3 grid(((a.dw + 3) / 4 + 63) / 64, (a.dh + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_resize_exact, grid, dim3(64, 4), 0, s, a);
+    dim3 grid(((a.dw + 3) / 4 + 63) / 64, (a.dh + 15) / 16, n_frames);
+    if(a.window12) // every quad's source pixels fit the aligned 12-byte window (checked on the host)
+        hipLaunchKernelGGL(k_resize_exact<true>, grid, dim3(64, 4), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_resize_exact<false>, grid, dim3(64, 4), 0, s, a);
 }
 
-// ---- whole-level FAST-9/16 score plane --------------------------------------------------------------------------
+// ---- whole-level FAST-9/16 with 3x3 non-max suppression, per 64x64 tile -------------------------------------------
 // score(x, y) = cornerScore<16> when the pixel passes the 9-contiguous test at `thr`, else 0, for 3 <= x < w-3,
-// 3 <= y < h-3 (FAST_t's tested range); everything else 0.  One workgroup per 64x64 tile: the 70x70 pixels it
-// needs are staged in LDS, the 4-point compass test rejects most pixels, the survivors are compacted into an
-// LDS list and scored densely (same arc-score formulation as k_fast_cells: S = max over the 16 arcs of 9 of
-// min(d) resp. min(-d), minus 1; the pixel is a corner iff S >= thr).
-constexpr int kSP = 72; // LDS tile pitch
+// 3 <= y < h-3 (FAST_t's tested range); a keypoint is a pixel whose score is strictly greater than its 8 neighbours'.
+// One workgroup per 64x64 tile: the 72x72 pixels it needs are staged in LDS, scores are computed for the tile plus a
+// one-pixel ring (66x66: the neighbours of the tile's own pixels), the 4-point compass test rejects most pixels, the
+// survivors are compacted into an LDS list and scored densely (same arc-score formulation as k_fast_cells:
+// S = max over the 16 arcs of 9 of min(d) resp. min(-d), minus 1; corner iff S >= thr).  Keypoints inside the
+// runByImageBorder(edge) rectangle are appended to the level's list (one global atomic per wave); the list is put into
+// FAST's raster order by k_cv_select.
+constexpr int kSP = 72; // LDS tile pitch = tile width 64 + 2 * (3 + 1)
+constexpr int kSc = 68; // score-map pitch (66 used)
 
 __device__ __forceinline__ int cv_min3(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int cv_max3(int a, int b, int c) { return max(max(a, b), c); }
@@ -95,39 +144,44 @@ __device__ __forceinline__ int cv_arc_score(const int (&d)[16])
     return max(q0, -q1) - 1;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ plane,
-                                                    Geometry g, int level, int tiles_x, int thr)
+__global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ pyr, Geometry g, int level, int tiles_x,
+                                                    int thr, CvSelectArgs a)
 {
-    __shared__ uint8_t tile[70 * kSP];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[64 * 64];
-    __shared__ uint16_t list[64 * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[72 * kSP];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kSc];
+    __shared__ uint16_t list[66 * 66];
     __shared__ uint32_t n_list;
 
     const LevelGeom& lv = g.lv[level];
     const int w = lv.w, h = lv.h, pitch = lv.pitch;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int X0 = tx * 64, Y0 = ty * 64; // the tile's output block; staged pixels start at (X0-3, Y0-3)
+    const int X0 = tx * 64, Y0 = ty * 64; // the tile's own block; scores cover (X0-1, Y0-1) + 66x66, pixels (X0-4, Y0-4) + 72x72
     const size_t frame = blockIdx.y + g.frame0;
     const uint8_t* src = pyr + frame * g.slab + lv.offset;
     const int tid = threadIdx.x;
 
-    for(int i = tid; i < 70 * 70; i += 256)
+    for(int i = tid; i < 72 * 18; i += 256) // 72 rows x 18 dwords (4 pixels each)
     {
-        const int r = i / 70, c = i - r * 70;
-        const int y = min(max(Y0 - 3 + r, 0), h - 1), x = min(max(X0 - 3 + c, 0), w - 1); // clamped: only read by untested pixels
-        tile[r * kSP + c] = src[(size_t)y * pitch + x];
+        const int r = i / 18, q = i - r * 18;
+        const int y = min(max(Y0 - 4 + r, 0), h - 1), x = X0 - 4 + 4 * q;
+        uint32_t v;
+        if(x >= 0 && x + 3 < pitch) // X0 and the pitch are multiples of 4: aligned dword inside the row
+            v = *reinterpret_cast<const uint32_t*>(src + (size_t)y * pitch + x);
+        else
+            v = 0; // outside the level: only ever read by pixels that are not tested
+        reinterpret_cast<uint32_t*>(tile)[r * (kSP / 4) + q] = v;
     }
-    for(int i = tid; i < 64 * 64 / 4; i += 256)
+    for(int i = tid; i < 66 * kSc / 4; i += 256)
         reinterpret_cast<uint32_t*>(sc)[i] = 0;
     if(tid == 0)
         n_list = 0;
     __syncthreads();
 
-    // compass test: a 9-arc contains two adjacent compass points of one polarity
-    for(int i = tid; i < 64 * 64; i += 256)
+    // compass test over the 66x66 scored region: a 9-arc contains two adjacent compass points of one polarity
+    for(int i = tid; i < 66 * 66; i += 256)
     {
-        const int ly = i >> 6, lx = i & 63;
-        const int x = X0 + lx, y = Y0 + ly;
+        const int ly = i / 66, lx = i - ly * 66;
+        const int x = X0 - 1 + lx, y = Y0 - 1 + ly;
         bool keep = false;
         if(x >= 3 && x < w - 3 && y >= 3 && y < h - 3)
         {
@@ -139,10 +193,11 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         const unsigned long long m = __ballot(keep);
         if(m)
         {
+            const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
-            if((tid & 63) == (__ffsll((long long)m) - 1))
+            if((tid & 63) == leader)
                 base = atomicAdd(&n_list, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+            base = (uint32_t)__shfl((int)base, leader);
             if(keep)
                 list[base + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
         }
@@ -152,7 +207,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
     for(uint32_t i = tid; i < n; i += 256)
     {
         const int idx = list[i];
-        const int ly = idx >> 6, lx = idx & 63;
+        const int ly = idx / 66, lx = idx - ly * 66;
         const uint8_t* p = &tile[(ly + 3) * kSP + lx + 3];
         const int v = p[0];
         int d[16];
@@ -174,104 +229,56 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         d[15] = v - p[3 * kSP - 1];
         const int s = cv_arc_score(d);
         if(s >= thr && s > 0)
-            sc[idx] = (uint8_t)s;
+            sc[ly * kSc + lx] = (uint8_t)s;
     }
     __syncthreads();
-    // store the 64x64 block (rows beyond the level, or dwords beyond its pitch, are not written)
-    uint8_t* dst = plane + frame * g.slab + lv.offset;
-    for(int i = tid; i < 64 * 16; i += 256)
+    // 3x3 strict NMS over the listed pixels of the tile's own 64x64 block + runByImageBorder(edge)
+    const int e = a.edge;
+    uint32_t* out = a.cand + (frame * g.n_levels + level) * (size_t)a.cand_cap;
+    uint32_t* out_cnt = a.cand_cnt + frame * g.n_levels + level;
+    for(uint32_t i0 = 0; i0 < n; i0 += 256)
     {
-        const int ly = i >> 4, q = i & 15;
-        const int y = Y0 + ly, x = X0 + 4 * q;
-        if(y < h && x < pitch)
-            *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x) = reinterpret_cast<const uint32_t*>(sc)[i];
+        const uint32_t i = i0 + tid;
+        bool is_kp = false;
+        uint32_t packed = 0;
+        if(i < n)
+        {
+            const int idx = list[i];
+            const int ly = idx / 66, lx = idx - ly * 66;
+            const int x = X0 - 1 + lx, y = Y0 - 1 + ly;
+            const uint8_t* q = &sc[ly * kSc + lx];
+            const int s = q[0];
+            if(s != 0 && lx >= 1 && lx <= 64 && ly >= 1 && ly <= 64 && x >= e && x < w - e && y >= e && y < h - e)
+            {
+                const int m = max(max(max(q[-kSc - 1], q[-kSc]), max(q[-kSc + 1], q[-1])),
+                                  max(max(q[1], q[kSc - 1]), max(q[kSc], q[kSc + 1])));
+                is_kp = s > m;
+                packed = pack_kp(x, y, s);
+            }
+        }
+        const unsigned long long m = __ballot(is_kp);
+        if(m)
+        {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if((tid & 63) == leader)
+                base = atomicAdd(out_cnt, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, leader);
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+            if(is_kp && pos < (uint32_t)a.cand_cap)
+                out[pos] = packed;
+        }
     }
 }
 
-void launch_fast_score(const uint8_t* d_pyr, uint8_t* d_plane, const Geometry& g, int level, int thr, int frame0,
+void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int level, int thr, const CvSelectArgs& a, int frame0,
                        int n_frames, hipStream_t s)
 {
     const LevelGeom& lv = g.lv[level];
-    const int tiles_x = (lv.pitch + 63) / 64, tiles_y = (lv.h + 63) / 64;
+    const int tiles_x = (lv.w + 63) / 64, tiles_y = (lv.h + 63) / 64;
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_fast_score, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, s, d_pyr, d_plane, gg, level, tiles_x,
-                       thr);
-}
-
-// ---- 3x3 strict NMS + runByImageBorder + raster-order candidate list: one workgroup per (level, frame) ---------
-__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ plane, Geometry g, CvSelectArgs a)
-{
-    __shared__ uint32_t wsum[4];
-    const int level = blockIdx.x;
-    const size_t frame = blockIdx.y + g.frame0;
-    const LevelGeom& lv = g.lv[level];
-    const int w = lv.w, h = lv.h, pitch = lv.pitch, qpr = pitch >> 2; // dwords per row
-    const uint8_t* sc = plane + frame * g.slab + lv.offset;
-    uint32_t* out = a.cand + (frame * g.n_levels + level) * (size_t)a.cand_cap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e = a.edge;
-    // only rows / dwords that can hold a kept keypoint are scanned: e <= y < h - e, e <= x < w - e
-    const int y_lo = e, y_hi = h - e, q_lo = e >> 2, q_hi = min(qpr, ((w - e + 3) >> 2));
-    const int qn = max(q_hi - q_lo, 0), rows = max(y_hi - y_lo, 0);
-    const int total = qn * rows;
-    uint32_t running = 0;
-    for(int base = 0; base < total; base += 256)
-    {
-        const int i = base + tid;
-        uint32_t found = 0, packed[4];
-        if(i < total)
-        {
-            const int r = i / qn, q = q_lo + (i - r * qn), y = y_lo + r;
-            const uint32_t dw = *reinterpret_cast<const uint32_t*>(sc + (size_t)y * pitch + 4 * q);
-            if(dw != 0)
-            {
-#pragma unroll
-                for(int b = 0; b < 4; ++b)
-                {
-                    const int s = (int)((dw >> (8 * b)) & 0xFF), x = 4 * q + b;
-                    if(s != 0 && x >= e && x < w - e)
-                    {
-                        // every neighbour is inside the level here (e >= 1); untested pixels hold 0
-                        const uint8_t* p = sc + (size_t)y * pitch + x;
-                        const int m = max(max(max(p[-pitch - 1], p[-pitch]), max(p[-pitch + 1], p[-1])),
-                                          max(max(p[1], p[pitch - 1]), max(p[pitch], p[pitch + 1])));
-                        if(s > m)
-                            packed[found++] = pack_kp(x, y, s);
-                    }
-                }
-            }
-        }
-        // ordered compaction: exclusive prefix of `found` over the workgroup
-        uint32_t inc = found;
-#pragma unroll
-        for(int o = 1; o < 64; o <<= 1)
-        {
-            const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
-            inc += lane >= o ? t : 0;
-        }
-        if(lane == 63)
-            wsum[wave] = inc;
-        __syncthreads();
-        uint32_t pre = 0, tot = 0;
-        for(int k = 0; k < 4; ++k)
-        {
-            pre += k < wave ? wsum[k] : 0;
-            tot += wsum[k];
-        }
-        uint32_t pos = running + pre + inc - found;
-        for(uint32_t k = 0; k < found; ++k, ++pos)
-            if(pos < (uint32_t)a.cand_cap)
-                out[pos] = packed[k];
-        running += tot;
-        __syncthreads();
-    }
-    if(tid == 0)
-    {
-        a.cand_cnt[frame * g.n_levels + level] = min(running, (uint32_t)a.cand_cap);
-        if(running > (uint32_t)a.cand_cap)
-            atomicOr(a.flags, kFlagCandOverflow);
-    }
+    hipLaunchKernelGGL(k_fast_tiles, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, s, d_pyr, gg, level, tiles_x, thr, a);
 }
 
 // ---- retainBest(2n) by FAST score -> Harris -> retainBest(n) by Harris: one workgroup per (level, frame) -------
@@ -318,10 +325,52 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
     uint32_t* sel = a.sel + slot * (size_t)a.cand_cap;
     float* sresp = a.sel_resp + slot * (size_t)a.cand_cap;
     const uint8_t* img = pyr + frame * g.slab + lv.offset;
-    const int n = (int)a.cand_cnt[slot];
-    const int quota = a.quota[level];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
+    const int n_raw = (int)a.cand_cnt[slot];
+    if(n_raw > a.cand_cap && tid == 0)
+        atomicOr(a.flags, kFlagCandOverflow);
+    const int n = min(n_raw, a.cand_cap);
+    const int quota = a.quota[level];
+    // The tile kernel appended the level's keypoints in arrival order; FAST's own order — the order everything
+    // downstream is defined in — is raster (y, then x), which is ascending order of the packed words.  Bitonic sort
+    // in place (global memory, visible inside the workgroup after a barrier; a level has ~10^3 keypoints).
+    {
+        uint32_t* keys = a.cand + slot * (size_t)a.cand_cap;
+        int np2 = 1;
+        while(np2 < n)
+            np2 <<= 1;
+        // normalised bitonic network (every comparator ascending; the first step of a merge mirrors the upper half), so a
+        // length that is not a power of two only needs comparators reaching beyond n to be skipped
+        for(int size = 2; size <= np2; size <<= 1)
+            for(int stride = size >> 1; stride > 0; stride >>= 1)
+            {
+                for(int t = tid; t < (np2 >> 1); t += 256)
+                {
+                    int lo, hi;
+                    if(stride == (size >> 1))
+                    {
+                        const int grp = t / stride, off = t - grp * stride;
+                        lo = grp * size + off;
+                        hi = grp * size + size - 1 - off;
+                    }
+                    else
+                    {
+                        lo = (t / stride) * stride * 2 + (t % stride);
+                        hi = lo + stride;
+                    }
+                    if(hi < n)
+                    {
+                        const uint32_t x = keys[lo], y = keys[hi];
+                        if(x > y)
+                        {
+                            keys[lo] = y;
+                            keys[hi] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+    }
     // ordered compaction of a predicate over [0, count): returns the total; `emit(i, pos)` stores element i
     auto compact = [&](int count, auto&& pred, auto&& emit) -> int {
         uint32_t running = 0;
@@ -405,12 +454,11 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
         a.sel_cnt[slot] = (uint32_t)m2;
 }
 
-void launch_cv_select(const uint8_t* d_pyr, const uint8_t* d_plane, const Geometry& g, const CvSelectArgs& a, int frame0,
-                      int n_frames, hipStream_t s)
+void launch_cv_select(const uint8_t* d_pyr, const Geometry& g, const CvSelectArgs& a, int frame0, int n_frames,
+                      hipStream_t s)
 {
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_fast_nms, dim3(g.n_levels, n_frames), dim3(256), 0, s, d_plane, gg, a);
     hipLaunchKernelGGL(k_cv_select, dim3(g.n_levels, n_frames), dim3(256), 0, s, d_pyr, gg, a);
 }
 
