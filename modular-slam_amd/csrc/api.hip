@@ -410,6 +410,18 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
+    for(int k = 0; k < 4; ++k)
+    {
+        if(c->blur_stream[k])
+        {
+            (void)hipStreamSynchronize(c->blur_stream[k]);
+            (void)hipStreamDestroy(c->blur_stream[k]);
+        }
+        if(c->ev_blur_fork[k])
+            (void)hipEventDestroy(c->ev_blur_fork[k]);
+        if(c->ev_blur_join[k])
+            (void)hipEventDestroy(c->ev_blur_join[k]);
+    }
     if(c->ev_fork)
         (void)hipEventDestroy(c->ev_fork);
     for(int k = 0; k < 4; ++k)
@@ -489,6 +501,14 @@ static int create_impl(mslam_hip_ctx* c)
         {
             HIPCHK(c, hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+        }
+        const char* fb = getenv("MSLAM_HIP_FORK_BLUR");
+        c->fork_blur = fb && atoi(fb) != 0;
+        for(int k = 0; k < 4; ++k)
+        {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->blur_stream[k], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_blur_fork[k], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_blur_join[k], hipEventDisableTiming));
         }
     }
     // tables
@@ -838,11 +858,31 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             launch_fast(c->d_pyr, g, c->d_cells, c->d_cell_cnt, c->d_cell_kp, c->p.ini_fast_thr, c->p.min_fast_thr, f0,
                         nf, cs);
         }
+        const bool forked = c->fork_blur && !c->profiling;
+        if(forked)
+        {
+            // quadtree (latency-bound, LDS-heavy) and blur (vector-ALU-bound, no LDS) only read the pyramid: side by side
+            HIPCHK(c, hipEventRecord(c->ev_blur_fork[k], cs));
+            HIPCHK(c, hipStreamWaitEvent(c->blur_stream[k], c->ev_blur_fork[k], 0));
+            {
+                StageScope t(c, "blur", c->blur_stream[k]);
+                launch_blur(c->d_pyr, c->d_blur, g, f0, nf, c->blur_stream[k]);
+            }
+            HIPCHK(c, hipEventRecord(c->ev_blur_join[k], c->blur_stream[k]));
+        }
         {
             StageScope t(c, "quadtree", cs);
             launch_quadtree(g, c->quad, f0, nf, cs);
         }
+        if(forked)
+            HIPCHK(c, hipStreamWaitEvent(cs, c->ev_blur_join[k], 0));
+        else
+        {
+            StageScope t(c, "blur", cs);
+            launch_blur(c->d_pyr, c->d_blur, g, f0, nf, cs);
+        }
         } // in-tree detector
+        if(cv_mode)
         {
             StageScope t(c, "blur", cs);
             launch_blur(c->d_pyr, c->d_blur, g, f0, nf, cs);

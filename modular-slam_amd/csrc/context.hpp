@@ -45,6 +45,10 @@ struct mslam_hip_ctx
     int n_side = 2;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the blur of a chunk runs on a stream of its own beside the chunk's quadtree (both only read the pyramid)
+    hipStream_t blur_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_blur_fork[4] = {nullptr, nullptr, nullptr, nullptr}, ev_blur_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool fork_blur = false;
     std::string err;
 
     // host copies of the tables

@@ -48,6 +48,57 @@ int main(int argc, char** argv)
         std::unique_ptr<mslam::IOrbFeatureDetector> detector = makeDetector();
         std::unique_ptr<mslam::IOrbMatcher> matcher = makeMatcher();
         std::printf("loaded %s\n", detector && matcher ? "ok" : "null");
+        if(argc == 4 && std::strcmp(argv[2], "--pnp") == 0)
+        {
+            // scene file: u32 n, then n x (3 f64 landmark, 2 f64 image point), then the initial sensor pose (3 f64 position,
+            // 4 f64 quaternion w x y z) and fx fy cx cy
+            std::ifstream in(argv[3], std::ios::binary);
+            std::uint32_t n = 0;
+            in.read(reinterpret_cast<char*>(&n), 4);
+            std::vector<std::shared_ptr<mslam::Landmark<mslam::Vector3>>> landmarks;
+            std::vector<mslam::Vector2> points;
+            for(std::uint32_t i = 0; i < n; ++i)
+            {
+                double v[5];
+                in.read(reinterpret_cast<char*>(v), sizeof(v));
+                auto lm = std::make_shared<mslam::Landmark<mslam::Vector3>>();
+                lm->id = i;
+                lm->state = mslam::Vector3(v[0], v[1], v[2]);
+                landmarks.push_back(lm);
+                points.emplace_back(v[3], v[4]);
+            }
+            double pose[7], cam[4];
+            in.read(reinterpret_cast<char*>(pose), sizeof(pose));
+            if(!in.read(reinterpret_cast<char*>(cam), sizeof(cam)))
+            {
+                std::fprintf(stderr, "cannot read %s\n", argv[3]);
+                return 5;
+            }
+            auto makePnp = mslam::loadFactoryMethod<mslam::ISlam3dPnp>(argv[1], "hipRansacPnpFactory");
+            std::unique_ptr<mslam::ISlam3dPnp> pnp = makePnp();
+            mslam::CameraParameters cp;
+            cp.focal = mslam::Vector2(cam[0], cam[1]);
+            cp.principalPoint = mslam::Vector2(cam[2], cam[3]);
+            cp.factor = 1.0f / 5000.0f;
+            pnp->setCameraParameters(cp);
+            mslam::slam3d::SensorState initial;
+            initial.position = mslam::Vector3(pose[0], pose[1], pose[2]);
+            initial.orientation = mslam::Quaternion(pose[3], pose[4], pose[5], pose[6]);
+            const auto result = pnp->solvePnp(landmarks, points, initial);
+            if(!result)
+            {
+                std::printf("pnp none\n");
+                return 0;
+            }
+            std::size_t inl = 0;
+            for(bool b : result->inliers)
+                inl += b ? 1 : 0;
+            std::printf("pnp position %.17g %.17g %.17g orientation %.17g %.17g %.17g %.17g inliers %zu\n",
+                        result->pose.position.x(), result->pose.position.y(), result->pose.position.z(),
+                        result->pose.orientation.w(), result->pose.orientation.x(), result->pose.orientation.y(),
+                        result->pose.orientation.z(), inl);
+            return 0;
+        }
         if(argc >= 7 && std::strcmp(argv[2], "--bow") == 0)
         {
             setenv("MSLAM_ORB_VOCABULARY", argv[3], 1); // the reference hard-codes "orbvoc.dbow3" in the working directory

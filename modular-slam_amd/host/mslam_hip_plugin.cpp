@@ -8,6 +8,7 @@
 //   HipOrbMatcher     : IFeatureMatcher<u8,32>             drop-in for OrbOpenCvMatcher (orb_feature.cpp:84-130)
 //   HipOrbRelocalizer : IRelocalizer                       what OrbRelocalizer is wired for
 //                                                           (orb_relocalizer.cpp:26-50, rgbd_feature_frontend.cpp:153,176)
+//   HipRansacPnp      : IPnpAlgorithm<SensorState,Vector3>  drop-in for OpenCvRansacPnp (cv_ransac_pnp.cpp:14-85)
 //   HipLoopDetector   : ILoopDetector                      (loop_detection.hpp:10-15, rgbd_feature_frontend.cpp:202);
 //                                                           both sit on ONE shared BoW database
 //
@@ -20,6 +21,7 @@
 #include "../../include/mslam_hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -297,6 +299,84 @@ class HipLoopDetector : public IOrbLoopDetector
     std::shared_ptr<BowDatabase> db;
 };
 
+// drop-in for OpenCvRansacPnp (cv_ransac_pnp.cpp:14-85): the same conversions around the solver call — landmark states and
+// image points cast to float (:22-40), the initial sensor pose turned into the world -> camera transform and its rotation
+// into a Rodrigues vector (:42-50), cv::solvePnPRansac's arguments (useExtrinsicGuess, 100 iterations, 5 px; :56-57), and
+// the result inverted back into a sensor pose (:65-78).
+class HipRansacPnp : public ISlam3dPnp
+{
+  public:
+    std::optional<PnpResult> solvePnp(const std::vector<std::shared_ptr<Landmark<Vector3>>>& landmarks,
+                                      const std::vector<Vector2>& sensorPoints, const slam3d::SensorState& initial) override
+    {
+        if(landmarks.size() != sensorPoints.size() || landmarks.size() < 4) // cv::solvePnPRansac asserts npoints >= 4
+            return std::nullopt;
+        const std::size_t n = landmarks.size();
+        obj.resize(3 * n);
+        img.resize(2 * n);
+        for(std::size_t i = 0; i < n; ++i)
+        {
+            obj[3 * i] = static_cast<float>(landmarks[i]->state.x());
+            obj[3 * i + 1] = static_cast<float>(landmarks[i]->state.y());
+            obj[3 * i + 2] = static_cast<float>(landmarks[i]->state.z());
+            img[2 * i] = static_cast<float>(sensorPoints[i].x());
+            img[2 * i + 1] = static_cast<float>(sensorPoints[i].y());
+        }
+        // toCameraCoordinateSystemProjection (projection.cpp:19-28)
+        const auto inverse = initial.orientation.inverse();
+        const Vector3 t0 = -(inverse * initial.position);
+        double rvec[3], tvec[3] = {t0.x(), t0.y(), t0.z()};
+        toRodrigues(inverse.w(), inverse.x(), inverse.y(), inverse.z(), rvec);
+        mask.assign(n, 0);
+        int nInliers = 0;
+        ctx.ensure(0, 0);
+        const int rc = mslam_hip_pnp_ransac(ctx.h, obj.data(), img.data(), static_cast<int>(n), cameraParams.focal.x(),
+                                            cameraParams.focal.y(), cameraParams.principalPoint.x(),
+                                            cameraParams.principalPoint.y(), 1, 100, 5.0, 0, rvec, tvec, mask.data(), &nInliers);
+        if(rc == MSLAM_HIP_E_NO_MODEL)
+        {
+            std::fprintf(stderr, "[error] Didnt find pnp solution\n"); // cv_ransac_pnp.cpp:61
+            return std::nullopt;
+        }
+        if(rc != MSLAM_HIP_OK)
+            raise(ctx.h, "mslam_hip_pnp_ransac", rc);
+        // :65-78: the camera rotation as angle-axis, inverted = the sensor orientation; position = -(orientation * t)
+        const double angle = std::sqrt(rvec[0] * rvec[0] + rvec[1] * rvec[1] + rvec[2] * rvec[2]);
+        double w = 1, x = 0, y = 0, z = 0;
+        if(angle > 0)
+        {
+            const double s = std::sin(0.5 * angle) / angle;
+            w = std::cos(0.5 * angle), x = rvec[0] * s, y = rvec[1] * s, z = rvec[2] * s;
+        }
+        PnpResult result;
+        result.pose.orientation = Quaternion(w, x, y, z).inverse();
+        result.pose.position = -(result.pose.orientation * Vector3(tvec[0], tvec[1], tvec[2]));
+        result.inliers.resize(n, false);
+        for(std::size_t i = 0; i < n; ++i)
+            result.inliers[i] = mask[i] != 0;
+        return result;
+    }
+
+  private:
+    static void toRodrigues(double w, double x, double y, double z, double r[3])
+    {
+        // Eigen::AngleAxisd(q): angle = 2 atan2(|v|, |w|), axis = v / |v| (sign folded for w < 0)
+        double nv = std::sqrt(x * x + y * y + z * z);
+        if(nv < 1e-300)
+        {
+            r[0] = r[1] = r[2] = 0;
+            return;
+        }
+        if(w < 0)
+            nv = -nv;
+        const double angle = 2.0 * std::atan2(nv, std::fabs(w));
+        r[0] = x / nv * angle, r[1] = y / nv * angle, r[2] = z / nv * angle;
+    }
+    Ctx ctx;
+    std::vector<float> obj, img;
+    std::vector<std::uint8_t> mask;
+};
+
 // ---- factories + aliases (what loadFactoryMethod<T>(lib, name) imports) -------------------------------
 std::unique_ptr<IOrbFeatureDetector> createHipOrbDetector() { return std::make_unique<HipOrbDetector>(); }
 // drop-in for OrbOpenCvDetector (orb_feature.cpp:25,33-65; wired by src/app/slam/rgbd_slam.cpp:74-76).  The reference leaves
@@ -308,6 +388,7 @@ std::unique_ptr<IOrbFeatureDetector> createHipCvOrbDetector()
 std::unique_ptr<IOrbMatcher> createHipOrbMatcher() { return std::make_unique<HipOrbMatcher>(); }
 std::unique_ptr<IOrbRelocalizer> createHipOrbRelocalizer() { return std::make_unique<HipOrbRelocalizer>(); }
 std::unique_ptr<IOrbLoopDetector> createHipLoopDetector() { return std::make_unique<HipLoopDetector>(); }
+std::unique_ptr<ISlam3dPnp> createHipRansacPnp() { return std::make_unique<HipRansacPnp>(); }
 
 } // namespace mslam
 
@@ -316,3 +397,4 @@ MSLAM_DLL_ALIAS(mslam::createHipCvOrbDetector, hipCvOrbDetectorFactory)
 MSLAM_DLL_ALIAS(mslam::createHipOrbMatcher, hipOrbMatcherFactory)
 MSLAM_DLL_ALIAS(mslam::createHipOrbRelocalizer, hipOrbRelocalizerFactory)
 MSLAM_DLL_ALIAS(mslam::createHipLoopDetector, loopDetection) // key used by test/plugin_config.json
+MSLAM_DLL_ALIAS(mslam::createHipRansacPnp, hipRansacPnpFactory)

@@ -16,31 +16,24 @@
 #ifdef MSLAM_USE_REFERENCE_HEADERS
 #include "modular_slam/loop_detection.hpp"
 #include "modular_slam/orb_feature.hpp"
+#include "modular_slam/pnp.hpp"
 #include "modular_slam/relocalizer.hpp"
 #include "modular_slam/types/slam3d_types.hpp"
 #else
 
 #include <array>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <optional>
 #include <vector>
+
+#include "mslam_camera.hpp"
 
 namespace mslam
 {
 using Id = std::uint64_t;
-
-// Eigen::Vector2d stand-in: 16-byte aligned pair of doubles with x()/y() accessors
-struct alignas(16) Vector2
-{
-    double v[2]{0, 0};
-    Vector2() = default;
-    Vector2(double x, double y) : v{x, y} {}
-    double& x() { return v[0]; }
-    double& y() { return v[1]; }
-    double x() const { return v[0]; }
-    double y() const { return v[1]; }
-};
 
 struct Size
 {
@@ -99,14 +92,76 @@ struct Keyframe
     StateType state;
 };
 
+// Eigen::Vector3d / Eigen::Quaterniond stand-ins: only what the adapters touch (types/basic_types.hpp)
+struct Vector3
+{
+    double v[3]{0, 0, 0};
+    Vector3() = default;
+    Vector3(double x, double y, double z) : v{x, y, z} {}
+    double x() const { return v[0]; }
+    double y() const { return v[1]; }
+    double z() const { return v[2]; }
+    Vector3 operator-() const { return Vector3(-v[0], -v[1], -v[2]); }
+};
+struct Quaternion
+{
+    double q[4]{1, 0, 0, 0}; // w, x, y, z
+    Quaternion() = default;
+    Quaternion(double w, double x, double y, double z) : q{w, x, y, z} {}
+    double w() const { return q[0]; }
+    double x() const { return q[1]; }
+    double y() const { return q[2]; }
+    double z() const { return q[3]; }
+    Quaternion inverse() const // unit quaternion
+    {
+        return Quaternion(q[0], -q[1], -q[2], -q[3]);
+    }
+    Vector3 operator*(const Vector3& p) const // rotate
+    {
+        const double w = q[0], x = q[1], y = q[2], z = q[3];
+        const double tx = 2 * (y * p.z() - z * p.y()), ty = 2 * (z * p.x() - x * p.z()), tz = 2 * (x * p.y() - y * p.x());
+        return Vector3(p.x() + w * tx + (y * tz - z * ty), p.y() + w * ty + (z * tx - x * tz), p.z() + w * tz + (x * ty - y * tx));
+    }
+};
+
+// types/state.hpp, types/landmark.hpp, sensors/camera_parameters.hpp
+template <typename PositionType, typename OrientationType>
+struct State
+{
+    PositionType position;
+    OrientationType orientation;
+};
+template <typename StateType>
+struct Landmark
+{
+    Id id;
+    StateType state;
+};
 namespace slam3d
 {
-struct SensorState
-{
-    double position[3]{0, 0, 0};
-    double orientation[4]{1, 0, 0, 0};
-};
+using SensorState = State<Vector3, Quaternion>;
 } // namespace slam3d
+
+// pnp.hpp:14-36 (PnpResult::inliers is a boost::dynamic_bitset there)
+template <typename SensorStateType, typename LandmarkStateType>
+class IPnpAlgorithm
+{
+  public:
+    struct PnpResult
+    {
+        SensorStateType pose;
+        std::vector<bool> inliers;
+    };
+    virtual std::optional<PnpResult> solvePnp(const std::vector<std::shared_ptr<Landmark<LandmarkStateType>>>& landmarks,
+                                              const std::vector<Vector2>& imgPoints,
+                                              const SensorStateType& initial = SensorStateType()) = 0;
+    void setCameraParameters(const CameraParameters& newParameters) { cameraParams = newParameters; }
+    [[nodiscard]] const CameraParameters& cameraParameters() const { return cameraParams; }
+    virtual ~IPnpAlgorithm() = default;
+
+  protected:
+    CameraParameters cameraParams;
+};
 
 template <typename StateType, typename DescriptorType, int DescriptorLength>
 class IRelocalizer
@@ -139,4 +194,5 @@ namespace mslam
 static_assert(sizeof(OrbKeypoint) == 64, "OrbKeypoint is expected to be a 64-byte record");
 using IOrbRelocalizer = IRelocalizer<slam3d::SensorState, std::uint8_t, 32>;
 using IOrbLoopDetector = ILoopDetector<slam3d::SensorState>;
+using ISlam3dPnp = IPnpAlgorithm<slam3d::SensorState, Vector3>;
 } // namespace mslam

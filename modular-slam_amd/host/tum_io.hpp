@@ -23,6 +23,8 @@
 #include <vector>
 #include <zlib.h>
 
+#include "mslam_camera.hpp"
+
 namespace mslam
 {
 
@@ -31,13 +33,6 @@ struct RgbdFilePaths // sensors/rgbd_file_provider.hpp
     std::vector<std::string> rgbPaths;
     std::vector<std::string> depthPaths;
     std::vector<double> timestamps;
-};
-
-struct CameraParameters // types/depth_frame.hpp
-{
-    float focal[2];
-    float principalPoint[2];
-    float factor;
 };
 
 // rgbd_file_provider.cpp:109-134: "timestamp rgbPath <ignored> depthPath" per line, paths relative to the
@@ -65,7 +60,11 @@ inline RgbdFilePaths readTumRgbdDataset(const std::filesystem::path& tumFile)
 // rgbd_file_provider.cpp:136-147
 inline CameraParameters tumRgbdCameraParams()
 {
-    return CameraParameters{{525.f, 525.f}, {319.5f, 239.5f}, 1.f / 5000.f};
+    CameraParameters p; // rgbd_file_provider.cpp:136-145
+    p.focal = Vector2(525.0, 525.0);
+    p.principalPoint = Vector2(319.5, 239.5);
+    p.factor = 1.f / 5000.f;
+    return p;
 }
 
 struct DecodedImage

@@ -56,9 +56,9 @@ int main(int argc, char** argv)
             std::snprintf(name, sizeof name, "%s%04d", argv[3], i);
             write_file(std::string(name) + ".bgr", f->rgb.data(), f->rgb.size());
             write_file(std::string(name) + ".depth16", f->depth.data(), f->depth.size() * 2);
-            std::printf("%.6f %d %d %g %g %g %g %.9g\n", f->timestamp, f->width, f->height, f->cameraParameters.focal[0],
-                        f->cameraParameters.focal[1], f->cameraParameters.principalPoint[0],
-                        f->cameraParameters.principalPoint[1], f->cameraParameters.factor);
+            std::printf("%.6f %d %d %g %g %g %g %.9g\n", f->timestamp, f->width, f->height, f->cameraParameters.focal.x(),
+                        f->cameraParameters.focal.y(), f->cameraParameters.principalPoint.x(),
+                        f->cameraParameters.principalPoint.y(), f->cameraParameters.factor);
             ++i;
         }
         std::printf("end after %d frames, recentData %s\n", i, prov.recentData() ? "set" : "null");

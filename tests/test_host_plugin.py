@@ -29,7 +29,7 @@ def built():
 def test_plugin_exports_boost_style_aliases(built):
     out = subprocess.check_output(["nm", "-D", PLUGIN]).decode()
     for alias in ("hipOrbDetectorFactory", "hipCvOrbDetectorFactory", "hipOrbMatcherFactory", "hipOrbRelocalizerFactory",
-                  "loopDetection"):
+                  "loopDetection", "hipRansacPnpFactory"):
         assert any(line.split()[-1] == alias and line.split()[-2] in "DdBb" for line in out.splitlines()), alias
     sec = subprocess.check_output(["readelf", "-S", PLUGIN]).decode()
     assert "boostdll" in sec  # the section BOOST_DLL_ALIAS uses
@@ -139,3 +139,44 @@ def test_plugin_cv_orb_detector(built, orc, bundled_frames, tmp_path):
     for a, b in zip(fi, ti):
         h = _fnv(struct.pack("<QQ", int(a), int(b)), h)
     assert "match 1 pairs %d fnv %08x" % (len(fi), h) in lines
+
+
+@pytest.mark.gpu
+def test_plugin_pnp(built, tmp_path):
+    """hipRansacPnpFactory: the OpenCvRansacPnp drop-in (cv_ransac_pnp.cpp:14-85) through the loader — sensor pose in,
+    sensor pose out (the adapter does the world->camera inversions of :42-50 and :65-78 around the solver)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mslam_pnp_oracle as po
+    from test_pnp import CAM, scene, rot_err
+    obj, img, R, t, good = scene(21, n=500, outliers=0.25)
+    # the sensor pose (world frame) that corresponds to the camera transform (R, t): orientation R^T, position -R^T t
+    Rs, ps = R.T, -R.T @ t
+    # start from a perturbed sensor pose (what the frontend passes: the previous frame's pose)
+    R0s = Rs @ po.rodrigues([0.01, 0.02, -0.015])
+    p0s = ps + np.array([0.03, -0.02, 0.04])
+
+    def quat(Rm):   # w, x, y, z
+        w = np.sqrt(max(0.0, 1 + np.trace(Rm))) / 2
+        return np.array([w, (Rm[2, 1] - Rm[1, 2]) / (4 * w), (Rm[0, 2] - Rm[2, 0]) / (4 * w), (Rm[1, 0] - Rm[0, 1]) / (4 * w)])
+    path = tmp_path / "scene.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(obj)))
+        for P, uv in zip(obj.astype(np.float64), img.astype(np.float64)):
+            f.write(struct.pack("<5d", *P, *uv))
+        f.write(struct.pack("<7d", *p0s, *quat(R0s)))
+        f.write(struct.pack("<4d", *CAM))
+    r = subprocess.run([HARNESS, PLUGIN, "--pnp", str(path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("pnp position")][0].split()
+    pos = np.array([float(x) for x in line[2:5]])
+    q = np.array([float(x) for x in line[6:10]])
+    n_in = int(line[11])
+    w, x, y, z = q
+    Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    assert rot_err(Rq, Rs) < 0.1 and np.linalg.norm(pos - ps) < 0.03          # ground truth (sensor pose)
+    ref = po.pnp_ransac(obj, img, CAM, seed=0, guess=(R0s.T, -R0s.T @ p0s))
+    assert n_in == int(ref["mask"].sum())
+    assert rot_err(Rq, ref["R"].T) < 1e-5 and np.linalg.norm(pos - (-ref["R"].T @ ref["t"])) < 1e-6
