@@ -361,3 +361,38 @@ def test_flat_word_assignment(pkg, orc, descs):
     rw, rwt = V.words_flat(d)
     assert np.array_equal(gw, rw) and np.array_equal(gwt, rwt)
     c.close()
+
+
+def test_bow_edge_cases(pkg, orc):
+    """empty inputs, removal / clear bookkeeping and loud failures of the database entry points"""
+    blob = synth.make_vocabulary(10, 3)
+    V = orc.Vocabulary(blob)
+    c = pkg.Context(width=0, height=0, max_keypoints=1024)          # no detector buffers
+    with pytest.raises(pkg.MslamHipError) as e:
+        c.detect(np.zeros((480, 640, 3), np.uint8))
+    assert e.value.code == pkg.E_INVALID and "without a detector" in str(e.value)
+    c.bow_load(blob)
+    rng = np.random.default_rng(2)
+    d = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    assert len(c.bow_db_query(d, 5)[0]) == 0 and c.bow_db_size() == 0   # empty database
+    w, v = c.bow_transform(d[:0])                                        # no descriptors: empty vector
+    assert len(w) == 0
+    assert c.bow_db_add(d) == 0 and c.bow_db_add(d[:0]) == 1              # an entry without words is legal
+    ids, sc = c.bow_db_query(d, 5)
+    assert list(ids) == [0] and sc[0] == orc.bow_score_l1(*V.bow_vector(d), *V.bow_vector(d))
+    with pytest.raises(pkg.MslamHipError):
+        c.bow_db_remove(7)                                                # no such entry
+    c.bow_db_remove(0)
+    assert len(c.bow_db_query(d, 5)[0]) == 0 and c.bow_db_size() == 2     # removed entries keep their ids
+    c.bow_db_clear()
+    assert c.bow_db_size() == 0 and c.bow_db_add(d) == 0                  # ids restart after clear
+    assert list(c.bow_db_query(d, 5)[0]) == [0]
+    with pytest.raises(pkg.MslamHipError) as e:
+        c.bow_words(rng.integers(0, 256, (2000, 32), dtype=np.uint8))     # more descriptors than max_keypoints
+    assert e.value.code == pkg.E_INVALID
+    c.close()
+    c = pkg.Context(width=0, height=0, max_keypoints=16384)
+    with pytest.raises(pkg.MslamHipError) as e:                           # LDS budget of the scoring kernel, at load time
+        c.bow_load(blob)
+    assert e.value.code == pkg.E_INVALID and "LDS" in str(e.value)
+    c.close()

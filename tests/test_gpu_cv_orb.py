@@ -101,3 +101,16 @@ def test_cv_orb_batch_and_match(pkg, orc, synth_frames):
                 assert len(rf) > 100 and mc[t] == len(rf)
                 assert np.array_equal(mf[t, :mc[t]], rf) and np.array_equal(mt[t, :mc[t]], rt)
     c.close()
+
+
+def test_cv_orb_capacity_is_loud(pkg, synth_frames):
+    c = pkg.Context(width=640, height=480, detector=pkg.DETECTOR_CV_ORB, max_keypoints=300)
+    with pytest.raises(pkg.MslamHipError) as e:
+        c.detect(synth_frames[0])
+    assert e.value.code == pkg.E_CAPACITY
+    c.close()
+    c = pkg.Context(width=640, height=480, detector=pkg.DETECTOR_CV_ORB, max_candidates=64)   # FAST list too small
+    with pytest.raises(pkg.MslamHipError) as e:
+        c.detect(synth_frames[0])
+    assert e.value.code == pkg.E_CAPACITY and "candidates" in str(e.value)
+    c.close()
