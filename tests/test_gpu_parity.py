@@ -389,3 +389,27 @@ def test_bench_launch_shape_1000_frames(pkg, orc, synth_frames):
             assert mc[t] == len(rf) and np.array_equal(mf[t, :mc[t]], rf) and np.array_equal(mt[t, :mc[t]], rt), t
         assert (2, 2) in seen and np.array_equal(*seen[(2, 2)])   # identical predecessor: every match maps i -> i
     c.close()
+
+
+def test_soak_random_frames_both_detectors(pkg, orc):
+    """60 frames of varied content (textures, contrast, noise levels, seeds, sizes) through both detector modes: every
+    output array bit-identical to the oracle (the reference's in-tree extractor and its cv::ORB detector)"""
+    import synth
+    rng = np.random.default_rng(2024)
+    for (W, H) in ((640, 480), (424, 240), (848, 480)):
+        c0 = pkg.Context(width=W, height=H, max_keypoints=20000, max_candidates=65536)
+        c1 = pkg.Context(width=W, height=H, max_keypoints=20000, max_candidates=65536, detector=pkg.DETECTOR_CV_ORB)
+        base = synth.make_base(W, H, seed=int(rng.integers(1 << 30)))
+        for i in range(20):
+            f = synth.frame_from_base(base, int(rng.integers(0, 5000)), W, H, int(rng.integers(1 << 30))).astype(np.int16)
+            gain, off, noise = rng.uniform(0.3, 1.6), rng.integers(-40, 40), rng.choice([0, 0, 3, 12, 40])
+            f = f * gain + off + (rng.integers(-noise, noise + 1, f.shape) if noise else 0)
+            if i % 7 == 3:                           # a flat band: cells without any corner, fallback threshold, empty levels
+                f[H // 3:H // 2] = 90
+            f = np.clip(f, 0, 255).astype(np.uint8)
+            got, ref = c0.detect(f, max_out=20000), orc.detect(f, orc.params())
+            assert_same_detection(got, ref)
+            got, ref = c1.detect(f, max_out=20000), orc.cvorb_detect(f, orc.cvorb_params())
+            assert_same_detection(got, ref)
+        c0.close()
+        c1.close()
