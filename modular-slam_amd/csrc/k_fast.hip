@@ -59,13 +59,61 @@ __device__ __forceinline__ int arc_score(const int (&d)[16])
     return max(q0, -q1) - 1;
 }
 
+// Packed 3-input min / max of two 16-bit values per register.  gfx950 has no integer form, but positive floats order like
+// their bit patterns, so v_pk_minimum3_f16 / v_pk_maximum3_f16 ARE the unsigned 16-bit min3 / max3 for patterns between
+// 0x0400 and 0x7BFF (positive normal halves: no NaN, no denormal).  The arc score keeps its differences biased into that
+// range (d + 1280 in [1025, 1535]).
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+constexpr int kArcBias = 1280; // 0x0500
+
+// arc scores of TWO pixels at once: e[k] = (centre - circle pixel k) + kArcBias in each half
+__device__ __forceinline__ void arc_score2(const uint32_t (&e)[16], int& sa, int& sb)
+{
+    uint32_t mn3[16], mx3[16];
+#pragma unroll
+    for(int i = 0; i < 16; ++i)
+    {
+        mn3[i] = pk_min3(e[i], e[(i + 1) & 15], e[(i + 2) & 15]);
+        mx3[i] = pk_max3(e[i], e[(i + 1) & 15], e[(i + 2) & 15]);
+    }
+    uint32_t mn9[16], mx9[16];
+#pragma unroll
+    for(int i = 0; i < 16; ++i)
+    {
+        mn9[i] = pk_min3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
+        mx9[i] = pk_max3(mx3[i], mx3[(i + 3) & 15], mx3[(i + 6) & 15]);
+    }
+    uint32_t q0 = pk_max3(mn9[0], mn9[1], mn9[2]), q1 = pk_min3(mx9[0], mx9[1], mx9[2]);
+#pragma unroll
+    for(int i = 3; i < 15; i += 2)
+    {
+        q0 = pk_max3(q0, mn9[i], mn9[i + 1]);
+        q1 = pk_min3(q1, mx9[i], mx9[i + 1]);
+    }
+    q0 = pk_max3(q0, mn9[15], mn9[15]);
+    q1 = pk_min3(q1, mx9[15], mx9[15]);
+    sa = max((int)(q0 & 0xFFFFu) - kArcBias, kArcBias - (int)(q1 & 0xFFFFu)) - 1;
+    sb = max((int)(q0 >> 16) - kArcBias, kArcBias - (int)(q1 >> 16)) - 1;
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, Geometry g,
                                                     const CellDesc* __restrict__ cells, uint32_t* __restrict__ cell_cnt,
                                                     uint32_t* __restrict__ cell_kp, int ini_thr, int min_thr, int n_frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kScP];
-    __shared__ uint16_t cand[64 * 64 + 2];
+    __shared__ __attribute__((aligned(4))) uint16_t cand[64 * 64 + 2];
     constexpr uint32_t kDump = 64 * 64; // write-only slot for rejected pixels
     __shared__ uint32_t bitmap[64 * 2];
     __shared__ uint32_t n_cand;
@@ -127,8 +175,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
             const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
             // which of this lane's four columns 3+4i .. 6+4i are tested (x < cw - 3)
             const int xl = 3 + 4 * i4;
-            const uint32_t colmask = (xl < cw - 3 ? 1u : 0u) | (xl + 1 < cw - 3 ? 2u : 0u) | (xl + 2 < cw - 3 ? 4u : 0u) |
-                                     (xl + 3 < cw - 3 ? 8u : 0u);
+            // (as sign bits of the four bytes: the layout the packed compares deliver, see `keep` below)
+            const uint32_t colmask = (xl < cw - 3 ? 0x80u : 0u) | (xl + 1 < cw - 3 ? 0x8000u : 0u) |
+                                     (xl + 2 < cw - 3 ? 0x800000u : 0u) | (xl + 3 < cw - 3 ? 0x80000000u : 0u);
 #pragma unroll 1
             for(int it = 0; it < 4; ++it)
             {
@@ -151,14 +200,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
                         const s16x2 t2 = __builtin_bit_cast(s16x2, thr2);
                         const s16x2 cc = w(C), hi = cc + t2, lo = cc - t2;
                         const s16x2 p0 = w(D), p4 = w(Rt), p8 = w(U), p12 = w(Lf);
-                        // sign bit set <=> brighter than c + t (hi - p < 0) / darker than c - t (p - lo < 0)
-                        const uint32_t b0 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p0)), b4 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p4));
-                        const uint32_t b8 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p8)), b12 = __builtin_bit_cast(uint32_t, (s16x2)(hi - p12));
-                        const uint32_t d0 = __builtin_bit_cast(uint32_t, (s16x2)(p0 - lo)), d4 = __builtin_bit_cast(uint32_t, (s16x2)(p4 - lo));
-                        const uint32_t d8 = __builtin_bit_cast(uint32_t, (s16x2)(p8 - lo)), d12 = __builtin_bit_cast(uint32_t, (s16x2)(p12 - lo));
-                        k[h] = ((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12));
+                        // brighter: (p0 or p8 > c + t) and (p4 or p12 > c + t)  <=>  min(max(p0, p8), max(p4, p12)) > c + t
+                        // darker : (p0 or p8 < c - t) and (p4 or p12 < c - t)  <=>  max(min(p0, p8), min(p4, p12)) < c - t
+                        // (packed 16-bit min / max; the comparisons are the sign bits of packed subtractions)
+                        const s16x2 mb = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12));
+                        const s16x2 md = __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
+                        k[h] = __builtin_bit_cast(uint32_t, (s16x2)(hi - mb)) | __builtin_bit_cast(uint32_t, (s16x2)(md - lo));
                     }
-                    keep = (((k[0] >> 15) & 1u) | ((k[0] >> 30) & 2u) | ((k[1] >> 13) & 4u) | ((k[1] >> 28) & 8u)) & colmask;
+                    // the four results are the sign bits of the 16-bit lanes of k[0], k[1]: one v_perm puts their high bytes
+                    // side by side, pixel j's flag is then bit 8j + 7
+                    keep = __builtin_amdgcn_perm(k[1], k[0], 0x07050301u) & colmask;
                 }
                 // compaction: wave-wide inclusive scan of the per-lane counts with DPP adds (no LDS, no ballots);
                 // every lane then issues its four stores unconditionally, rejected pixels into a dump slot
@@ -187,7 +238,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 #pragma unroll
                     for(int k = 0; k < 4; ++k)
                     {
-                        const int m = __builtin_amdgcn_sbfe((int)keep, k, 1); // -1 when kept
+                        const int m = __builtin_amdgcn_sbfe((int)keep, 8 * k + 7, 1); // -1 when kept
                         uint32_t slot2;
                         asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(slot2) : "v"(m), "v"(pos2), "v"(dump2));
                         *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(cand) + slot2) = (uint16_t)(yx + k);
@@ -199,33 +250,41 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         __syncthreads();
         const uint32_t n = n_cand;
 
-        // ---- B. arc score of the survivors
-        for(uint32_t i = tid; i < n; i += 256)
+        // ---- B. arc score of the survivors, two per lane (packed 16-bit 3-input min / max)
+        for(uint32_t j = tid; 2 * j < n; j += 256)
         {
-            const uint32_t cxy = cand[i];
-            const int cy = (int)(cxy >> 8), cx = (int)(cxy & 0xFF);
-            const uint8_t* p = &tile[cy * kTileP + cx + kTileX];
-            const int v = p[0];
-            int d[16];
-            d[0] = v - p[3 * kTileP];
-            d[1] = v - p[3 * kTileP + 1];
-            d[2] = v - p[2 * kTileP + 2];
-            d[3] = v - p[kTileP + 3];
-            d[4] = v - p[3];
-            d[5] = v - p[-kTileP + 3];
-            d[6] = v - p[-2 * kTileP + 2];
-            d[7] = v - p[-3 * kTileP + 1];
-            d[8] = v - p[-3 * kTileP];
-            d[9] = v - p[-3 * kTileP - 1];
-            d[10] = v - p[-2 * kTileP - 2];
-            d[11] = v - p[-kTileP - 3];
-            d[12] = v - p[-3];
-            d[13] = v - p[kTileP - 3];
-            d[14] = v - p[2 * kTileP - 2];
-            d[15] = v - p[3 * kTileP - 1];
-            const int s = arc_score(d);
-            if(s >= thr && s > 0)
-                sc[(cy - 2) * kScP + (cx - 2)] = (uint8_t)s;
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(&cand[2 * j]); // entries 2j, 2j+1
+            const uint32_t ca = two & 0xFFFFu, cb = 2 * j + 1 < n ? two >> 16 : ca;  // an odd tail scores its last pixel twice
+            const int ay = (int)(ca >> 8), ax = (int)(ca & 0xFF), by = (int)(cb >> 8), bx = (int)(cb & 0xFF);
+            const uint8_t* pa = &tile[ay * kTileP + ax + kTileX];
+            const uint8_t* pb = &tile[by * kTileP + bx + kTileX];
+            // (centre + bias) of both pixels; the subtraction below never borrows from the upper half
+            const uint32_t vv = ((uint32_t)pa[0] + kArcBias) | (((uint32_t)pb[0] + kArcBias) << 16);
+            uint32_t e[16];
+#define MSLAM_E(k, off) e[k] = vv - ((uint32_t)pa[off] | ((uint32_t)pb[off] << 16))
+            MSLAM_E(0, 3 * kTileP);
+            MSLAM_E(1, 3 * kTileP + 1);
+            MSLAM_E(2, 2 * kTileP + 2);
+            MSLAM_E(3, kTileP + 3);
+            MSLAM_E(4, 3);
+            MSLAM_E(5, -kTileP + 3);
+            MSLAM_E(6, -2 * kTileP + 2);
+            MSLAM_E(7, -3 * kTileP + 1);
+            MSLAM_E(8, -3 * kTileP);
+            MSLAM_E(9, -3 * kTileP - 1);
+            MSLAM_E(10, -2 * kTileP - 2);
+            MSLAM_E(11, -kTileP - 3);
+            MSLAM_E(12, -3);
+            MSLAM_E(13, kTileP - 3);
+            MSLAM_E(14, 2 * kTileP - 2);
+            MSLAM_E(15, 3 * kTileP - 1);
+#undef MSLAM_E
+            int sa, sb;
+            arc_score2(e, sa, sb);
+            if(sa >= thr && sa > 0)
+                sc[(ay - 2) * kScP + (ax - 2)] = (uint8_t)sa;
+            if(sb >= thr && sb > 0)
+                sc[(by - 2) * kScP + (bx - 2)] = (uint8_t)sb;
         }
         __syncthreads();
 
