@@ -14,6 +14,7 @@
 // retainBest keeps the SET {response >= n-th largest} (ties kept); its ORDER in the reference comes from
 // std::nth_element / std::partition and is implementation-defined, so lists stay in FAST's raster order here.
 #include "common.hpp"
+#include "arc_score.hpp"
 
 namespace mslam
 {
@@ -122,28 +123,6 @@ void launch_resize_exact(const ExactResizeArgs& a, int n_frames, hipStream_t s)
 constexpr int kSP = 72; // LDS tile pitch = tile width 64 + 2 * (3 + 1)
 constexpr int kSc = 68; // score-map pitch (66 used)
 
-__device__ __forceinline__ int cv_min3(int a, int b, int c) { return min(min(a, b), c); }
-__device__ __forceinline__ int cv_max3(int a, int b, int c) { return max(max(a, b), c); }
-
-__device__ __forceinline__ int cv_arc_score(const int (&d)[16])
-{
-    int mn3[16], mx3[16];
-#pragma unroll
-    for(int i = 0; i < 16; ++i)
-    {
-        mn3[i] = cv_min3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-        mx3[i] = cv_max3(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-    }
-    int q0 = -1000, q1 = 1000;
-#pragma unroll
-    for(int i = 0; i < 16; ++i)
-    {
-        q0 = max(q0, cv_min3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]));
-        q1 = min(q1, cv_max3(mx3[i], mx3[(i + 3) & 15], mx3[(i + 6) & 15]));
-    }
-    return max(q0, -q1) - 1;
-}
-
 __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ pyr, Geometry g, int level, int tiles_x,
                                                     int thr, CvSelectArgs a)
 {
@@ -204,32 +183,38 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
     }
     __syncthreads();
     const uint32_t n = n_list;
-    for(uint32_t i = tid; i < n; i += 256)
+    for(uint32_t j = tid; 2 * j < n; j += 256) // two listed pixels per lane (arc_score.hpp)
     {
-        const int idx = list[i];
-        const int ly = idx / 66, lx = idx - ly * 66;
-        const uint8_t* p = &tile[(ly + 3) * kSP + lx + 3];
-        const int v = p[0];
-        int d[16];
-        d[0] = v - p[3 * kSP];
-        d[1] = v - p[3 * kSP + 1];
-        d[2] = v - p[2 * kSP + 2];
-        d[3] = v - p[kSP + 3];
-        d[4] = v - p[3];
-        d[5] = v - p[-kSP + 3];
-        d[6] = v - p[-2 * kSP + 2];
-        d[7] = v - p[-3 * kSP + 1];
-        d[8] = v - p[-3 * kSP];
-        d[9] = v - p[-3 * kSP - 1];
-        d[10] = v - p[-2 * kSP - 2];
-        d[11] = v - p[-kSP - 3];
-        d[12] = v - p[-3];
-        d[13] = v - p[kSP - 3];
-        d[14] = v - p[2 * kSP - 2];
-        d[15] = v - p[3 * kSP - 1];
-        const int s = cv_arc_score(d);
-        if(s >= thr && s > 0)
-            sc[ly * kSc + lx] = (uint8_t)s;
+        const int ia = list[2 * j], ib = 2 * j + 1 < n ? list[2 * j + 1] : ia;
+        const int ay = ia / 66, ax = ia - ay * 66, by = ib / 66, bx = ib - by * 66;
+        const uint8_t* pa = &tile[(ay + 3) * kSP + ax + 3];
+        const uint8_t* pb = &tile[(by + 3) * kSP + bx + 3];
+        const uint32_t vv = ((uint32_t)pa[0] + kArcBias) | (((uint32_t)pb[0] + kArcBias) << 16);
+        uint32_t e[16];
+#define MSLAM_E(k, off) e[k] = vv - ((uint32_t)pa[off] | ((uint32_t)pb[off] << 16))
+        MSLAM_E(0, 3 * kSP);
+        MSLAM_E(1, 3 * kSP + 1);
+        MSLAM_E(2, 2 * kSP + 2);
+        MSLAM_E(3, kSP + 3);
+        MSLAM_E(4, 3);
+        MSLAM_E(5, -kSP + 3);
+        MSLAM_E(6, -2 * kSP + 2);
+        MSLAM_E(7, -3 * kSP + 1);
+        MSLAM_E(8, -3 * kSP);
+        MSLAM_E(9, -3 * kSP - 1);
+        MSLAM_E(10, -2 * kSP - 2);
+        MSLAM_E(11, -kSP - 3);
+        MSLAM_E(12, -3);
+        MSLAM_E(13, kSP - 3);
+        MSLAM_E(14, 2 * kSP - 2);
+        MSLAM_E(15, 3 * kSP - 1);
+#undef MSLAM_E
+        int sa, sb;
+        arc_score2(e, sa, sb);
+        if(sa >= thr && sa > 0)
+            sc[ay * kSc + ax] = (uint8_t)sa;
+        if(sb >= thr && sb > 0)
+            sc[by * kSc + bx] = (uint8_t)sb;
     }
     __syncthreads();
     // 3x3 strict NMS over the listed pixels of the tile's own 64x64 block + runByImageBorder(edge)

@@ -9,9 +9,9 @@
 //   A. every tested pixel takes the 4-point compass test (a 9-arc always contains two adjacent
 //      compass points of one polarity), four pixels per lane with packed 16-bit compares on dword LDS
 //      reads; survivors are compacted into an LDS list with ballots;
-//   B. the list is processed densely (all 64 lanes busy): 16 circle reads and the arc score
+//   B. the list is processed densely (all 64 lanes busy), TWO pixels per lane: 16 circle reads each and the arc score
 //        S = max(max_arc min(d), max_arc min(-d)) - 1,   d = centre - circle pixel,
-//      over the 16 arcs of 9 pixels, with 3-input min/max.  For a pixel that passes the 9-contiguous
+//      over the 16 arcs of 9 pixels, with packed 16-bit 3-input min/max (arc_score.hpp).  For a pixel that passes the 9-contiguous
 //      test at threshold t this is OpenCV's cornerScore<16>(.., t), and it passes iff S >= t, so the
 //      test itself never has to be evaluated separately;
 //   C. listed pixels with S >= t are checked against their 8 neighbours in the LDS score map (strict >)
@@ -19,6 +19,7 @@
 //      output order with no dependence on atomic ordering.
 // If the cell is empty at the first threshold the same three steps run again with the fallback one.
 #include "common.hpp"
+#include "arc_score.hpp"
 
 namespace mslam
 {
@@ -29,83 +30,6 @@ constexpr int kScP = 68;   // score-map row pitch
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-
-__device__ __forceinline__ int arc_score(const int (&d)[16])
-{
-    // window-9 min and max over the circular sequence: two levels of 3-input ops
-    int mn3[16], mx3[16];
-#pragma unroll
-    for(int i = 0; i < 16; ++i)
-    {
-        mn3[i] = min3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-        mx3[i] = max3i(d[i], d[(i + 1) & 15], d[(i + 2) & 15]);
-    }
-    int mn9[16], mx9[16];
-#pragma unroll
-    for(int i = 0; i < 16; ++i)
-    {
-        mn9[i] = min3i(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
-        mx9[i] = max3i(mx3[i], mx3[(i + 3) & 15], mx3[(i + 6) & 15]);
-    }
-    int q0 = max3i(mn9[0], mn9[1], mn9[2]), q1 = min3i(mx9[0], mx9[1], mx9[2]);
-#pragma unroll
-    for(int i = 3; i < 15; i += 2)
-    {
-        q0 = max3i(q0, mn9[i], mn9[i + 1]);
-        q1 = min3i(q1, mx9[i], mx9[i + 1]);
-    }
-    q0 = max(q0, mn9[15]);
-    q1 = min(q1, mx9[15]);
-    return max(q0, -q1) - 1;
-}
-
-// Packed 3-input min / max of two 16-bit values per register.  gfx950 has no integer form, but positive floats order like
-// their bit patterns, so v_pk_minimum3_f16 / v_pk_maximum3_f16 ARE the unsigned 16-bit min3 / max3 for patterns between
-// 0x0400 and 0x7BFF (positive normal halves: no NaN, no denormal).  The arc score keeps its differences biased into that
-// range (d + 1280 in [1025, 1535]).
-__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t d;
-    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t d;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-constexpr int kArcBias = 1280; // 0x0500
-
-// arc scores of TWO pixels at once: e[k] = (centre - circle pixel k) + kArcBias in each half
-__device__ __forceinline__ void arc_score2(const uint32_t (&e)[16], int& sa, int& sb)
-{
-    uint32_t mn3[16], mx3[16];
-#pragma unroll
-    for(int i = 0; i < 16; ++i)
-    {
-        mn3[i] = pk_min3(e[i], e[(i + 1) & 15], e[(i + 2) & 15]);
-        mx3[i] = pk_max3(e[i], e[(i + 1) & 15], e[(i + 2) & 15]);
-    }
-    uint32_t mn9[16], mx9[16];
-#pragma unroll
-    for(int i = 0; i < 16; ++i)
-    {
-        mn9[i] = pk_min3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
-        mx9[i] = pk_max3(mx3[i], mx3[(i + 3) & 15], mx3[(i + 6) & 15]);
-    }
-    uint32_t q0 = pk_max3(mn9[0], mn9[1], mn9[2]), q1 = pk_min3(mx9[0], mx9[1], mx9[2]);
-#pragma unroll
-    for(int i = 3; i < 15; i += 2)
-    {
-        q0 = pk_max3(q0, mn9[i], mn9[i + 1]);
-        q1 = pk_min3(q1, mx9[i], mx9[i + 1]);
-    }
-    q0 = pk_max3(q0, mn9[15], mn9[15]);
-    q1 = pk_min3(q1, mx9[15], mx9[15]);
-    sa = max((int)(q0 & 0xFFFFu) - kArcBias, kArcBias - (int)(q1 & 0xFFFFu)) - 1;
-    sb = max((int)(q0 >> 16) - kArcBias, kArcBias - (int)(q1 >> 16)) - 1;
-}
 
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, Geometry g,
                                                     const CellDesc* __restrict__ cells, uint32_t* __restrict__ cell_cnt,
