@@ -130,6 +130,7 @@ __device__ __forceinline__ void wave_sum_dpp2(int a, int b, int& ra, int& rb)
 // Everything a wave needs about "its" keypoint is wave-uniform and kept in SGPRs (readlane).
 constexpr int kBatch = 16;
 constexpr int kWavesPerFrame = kBlocksPerFrame * 4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
 {
@@ -162,13 +163,15 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
 
     // per-lane constants: disc weights and this lane's four sampling pairs
     uint32_t wu[4], wv[4];
-    float4 pat[4];
+    f32x2 patX[4], patY[4]; // (x0, x1) and (y0, y1) of the lane's four pairs: operands of the packed-f32 rotation
 #pragma unroll
     for(int k = 0; k < 4; ++k)
     {
         wu[k] = a.orient_w[lane + 64 * k];
         wv[k] = a.orient_w[256 + lane + 64 * k];
-        pat[k] = reinterpret_cast<const float4*>(c_pattern_f)[lane + 64 * k];
+        const float4 q = reinterpret_cast<const float4*>(c_pattern_f)[lane + 64 * k];
+        patX[k] = f32x2{q.x, q.z};
+        patY[k] = f32x2{q.y, q.w};
     }
     const uint8_t* pyr = a.pyr + frame * g.slab;
     const uint8_t* blur = a.blur + frame * g.slab;
@@ -366,21 +369,27 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
             auto describe = [&](int k, int buf) {
                 const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ca), k));
                 const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sa), k));
-                const int sh = (int)(bc(my_sh, k) >> 4);
-                const uint8_t* ctr =
-                    reinterpret_cast<const uint8_t*>(patch[wave][buf]) + kPatchR * (kPatchDw * 4) + kPatchR + sh; // centre
+                // Both points of a pair are rotated at once with packed f32 multiplies / adds (v_pk_mul_f32, v_pk_add_f32:
+                // every product and sum is rounded on its own, as in the reference; the file is built with
+                // -ffp-contract=off).  cvRound (round-half-even) is the magic-number add: the f32 sum v + 1.5 * 2^23 has the
+                // bit pattern 0x4B400000 + rint(v) for |v| < 2^22, so row * 64 + col comes out of one shift-add on the bit
+                // patterns and the constant 65 * 0x4B400000 is folded into the (wave-uniform) centre offset, mod 2^32.
+                f32x2 ca2 = f32x2{ca, ca}, sa2 = f32x2{sa, sa};
+                asm volatile("" : "+v"(ca2), "+v"(sa2)); // keep them vector register pairs (not re-associated onto the scalars)
+                const f32x2 magic = f32x2{12582912.f, 12582912.f};
+                const uint8_t* lp = reinterpret_cast<const uint8_t*>(patch[wave][buf]);
+                const uint32_t ctr_off = (uint32_t)(kPatchR * (kPatchDw * 4) + kPatchR) + (bc(my_sh, k) >> 4) - 65u * 0x4B400000u;
                 unsigned long long bits[4];
 #pragma unroll
                 for(int t = 0; t < 4; ++t)
                 {
-                    const float4 q = pat[t];
                     // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
-                    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(q.x, sa), __fmul_rn(q.y, ca)));
-                    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(q.x, ca), __fmul_rn(q.y, sa)));
-                    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(q.z, sa), __fmul_rn(q.w, ca)));
-                    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(q.z, ca), __fmul_rn(q.w, sa)));
-                    const int v0 = ctr[__mul24(r0, kPatchDw * 4) + c0];
-                    const int v1 = ctr[__mul24(r1, kPatchDw * 4) + c1];
+                    const f32x2 rr = (patX[t] * sa2 + patY[t] * ca2) + magic;
+                    const f32x2 cc = (patX[t] * ca2 - patY[t] * sa2) + magic;
+                    const uint32_t i0 = (__float_as_uint(rr.x) << 6) + __float_as_uint(cc.x) + ctr_off;
+                    const uint32_t i1 = (__float_as_uint(rr.y) << 6) + __float_as_uint(cc.y) + ctr_off;
+                    const int v0 = lp[i0];
+                    const int v1 = lp[i1];
                     bits[t] = __ballot(v0 < v1);
                 }
                 if(lane < 4)
