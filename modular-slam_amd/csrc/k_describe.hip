@@ -9,6 +9,7 @@
 // LSB first, :614-625).  All float arithmetic is individually rounded (no FMA) and follows
 // the reference expression order; cvRound = round-half-even, cvFloor = floor.
 #include "common.hpp"
+#include <cstdlib>
 #include "../../include/mslam_orb_pattern.h"
 #include "../../include/mslam_sincos.h"
 
@@ -73,8 +74,8 @@ __device__ __forceinline__ float util_sin(float v)
     return util_cos(__fsub_rn(PI_2, v));
 }
 
-constexpr int kPatchR = 19;               // sample radius of the rotated pattern (orb_patch_radius_)
-constexpr int kPatchRows = 2 * kPatchR + 1; // 39
+constexpr int kPatchR = 18;               // the rotated pattern reaches |18| (its radius is 18.38; the reference keeps a 19-px border)
+constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 16;              // 64 bytes from a 16-byte aligned start cover the 39 needed ones
 constexpr int kPatchBufs = 4;            // LDS patch ring per wave: one being sampled, three in flight (2 / 3 / 4 / 5 / 6 slots: 0.59 / 0.56 / 0.55 / 0.57 / 0.68 ms per 500 frames)
 constexpr int kBlocksPerFrame = 32;
@@ -132,7 +133,7 @@ constexpr int kBatch = 16;
 constexpr int kWavesPerFrame = kBlocksPerFrame * 4;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
+__global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bpf)
 {
     __shared__ __attribute__((aligned(16))) uint32_t patch[4][kPatchBufs][kPatchRows * kPatchDw];
 
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     // workgroups of a frame are given ids with the same (id & 7): the two level slabs of a frame (1.9 MB)
     // are then gathered through ONE 4 MB L2 instead of being pulled into all eight.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int f_local = (slot / kBlocksPerFrame) * 8 + xcd;
+    const int f_local = (slot / bpf) * 8 + xcd;
     if(f_local >= a.n_frames)
         return;
-    const int bx = slot % kBlocksPerFrame;
+    const int bx = slot % bpf;
     const size_t frame = (size_t)f_local + g.frame0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
     }
     __builtin_amdgcn_s_waitcnt(0x0F70); // the table is in registers: no waits for it inside the batch loop
 
-    for(int base = (bx * 4 + wave) * kBatch; base < n_kp; base += kWavesPerFrame * kBatch)
+    for(int base = (bx * 4 + wave) * kBatch; base < n_kp; base += bpf * 4 * kBatch)
     {
         const int n_here = min(kBatch, n_kp - base); // wave-uniform
 
@@ -317,16 +318,33 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
         auto dma_patch = [&](int k, int buf) {
             const uint8_t* bsrc = blur + bc(my_poff, k);
             const uint32_t pitch = bc(my_pitch, k);
-#pragma unroll
-            for(int q = 0; q < 3; ++q)
+            // the 37 needed bytes of a row start `sh` bytes into its first 16-byte chunk: three chunks cover them when
+            // sh <= 11 (3 keypoints out of 4) — 111 lanes = TWO DMA instructions, rows packed at a 48-byte pitch;
+            // otherwise four chunks per row, 148 lanes = three instructions, 64-byte pitch, chunks XOR-swizzled by row
+            if((bc(my_sh, k) >> 4) <= 11u)
             {
-                const uint32_t t = (uint32_t)lane + 64u * q;
-                if(t < (uint32_t)(kPatchRows * 4))
-                    __builtin_amdgcn_global_load_lds(
-                        // LDS slot t holds row t >> 2, 16-byte chunk (t & 3) ^ ((row >> 1) & 3): the XOR spreads the rows
-                        // over the banks (see describe())
-                        (const __attribute__((address_space(1))) void*)(bsrc + __umul24(t >> 2, pitch) + 16u * ((t & 3u) ^ ((t >> 3) & 3u))),
-                        (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+#pragma unroll
+                for(int q = 0; q < 2; ++q)
+                {
+                    const uint32_t t = (uint32_t)lane + 64u * q;
+                    const uint32_t row = (t * 21846u) >> 16; // t / 3
+                    if(t < (uint32_t)(kPatchRows * 3))
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(bsrc + __umul24(row, pitch) + 16u * (t - 3u * row)),
+                            (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for(int q = 0; q < 3; ++q)
+                {
+                    const uint32_t t = (uint32_t)lane + 64u * q;
+                    if(t < (uint32_t)(kPatchRows * 4))
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(bsrc + __umul24(t >> 2, pitch) + 16u * ((t & 3u) ^ ((t >> 3) & 3u))),
+                            (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                }
             }
         };
         constexpr int kDepth = kPatchBufs - 1; // patches in flight beside the one being sampled
@@ -380,7 +398,10 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 asm volatile("" : "+v"(ca2), "+v"(sa2)); // keep them vector register pairs (not re-associated onto the scalars)
                 const f32x2 magic = f32x2{12582912.f, 12582912.f};
                 const uint8_t* lp = reinterpret_cast<const uint8_t*>(patch[wave][buf]);
-                const uint32_t ctr_off = (uint32_t)(kPatchR * (kPatchDw * 4) + kPatchR) + (bc(my_sh, k) >> 4) - 65u * 0x4B400000u;
+                const uint32_t shp = bc(my_sh, k) >> 4;
+                const bool three = shp <= 11u; // 48-byte row pitch (see dma_patch)
+                const uint32_t ctr_off = three ? (uint32_t)(kPatchR * 48 + kPatchR) + shp - 49u * 0x4B400000u
+                                               : (uint32_t)(kPatchR * 64 + kPatchR) + shp - 65u * 0x4B400000u;
                 unsigned long long bits[4];
 #pragma unroll
                 for(int t = 0; t < 4; ++t)
@@ -388,14 +409,20 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                     // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
                     const f32x2 rr = (patX[t] * sa2 + patY[t] * ca2) + magic;
                     const f32x2 cc = (patX[t] * ca2 - patY[t] * sa2) + magic;
-                    uint32_t i0 = (__float_as_uint(rr.x) << 6) + __float_as_uint(cc.x) + ctr_off; // row * 64 + byte in row
-                    uint32_t i1 = (__float_as_uint(rr.y) << 6) + __float_as_uint(cc.y) + ctr_off;
-                    // The kernel is bound by the LDS: with the plain 64-byte row pitch a byte's bank depends only on
-                    // (row & 1, column / 4) and the pattern's points crowd the central columns — 4.6 LDS cycles per 32-lane
-                    // gather.  The patch is therefore stored with its four 16-byte chunks XOR-swizzled by (row >> 1) & 3
-                    // (the DMA above fetches the chunks in that order): 3.1 cycles.
-                    i0 ^= (i0 >> 3) & 0x30u;
-                    i1 ^= (i1 >> 3) & 0x30u;
+                    const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y);
+                    uint32_t i0, i1;
+                    if(three)
+                    {
+                        i0 = (r0 << 5) + (r0 << 4) + __float_as_uint(cc.x) + ctr_off; // row * 48 + byte in row
+                        i1 = (r1 << 5) + (r1 << 4) + __float_as_uint(cc.y) + ctr_off;
+                    }
+                    else
+                    {
+                        i0 = (r0 << 6) + __float_as_uint(cc.x) + ctr_off; // row * 64 + byte in row
+                        i1 = (r1 << 6) + __float_as_uint(cc.y) + ctr_off;
+                        i0 ^= (i0 >> 3) & 0x30u; // chunk swizzle
+                        i1 ^= (i1 >> 3) & 0x30u;
+                    }
                     const int v0 = lp[i0];
                     const int v1 = lp[i1];
                     bits[t] = __ballot(v0 < v1);
@@ -419,16 +446,17 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a)
                 const int younger = min(kDepth, n_here - 1 - k);
                 if(k + kDepth < n_here)
                     dma_patch(k + kDepth, (k + kDepth) % kPatchBufs); // its ring slot was sampled in iteration k - 1
+                // (a patch is 2 or 3 instructions: counting 2 for every younger one is the safe side)
                 if(younger >= 5)
-                    __builtin_amdgcn_s_waitcnt(0x0F70 | 15);
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 10);
                 else if(younger == 4)
-                    __builtin_amdgcn_s_waitcnt(0x0F70 | 12);
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
                 else if(younger == 3)
-                    __builtin_amdgcn_s_waitcnt(0x0F70 | 9);
-                else if(younger == 2)
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+                else if(younger == 2)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
                 else if(younger == 1)
-                    __builtin_amdgcn_s_waitcnt(0x0F70 | 3);
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 2);
                 else
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
                 __builtin_amdgcn_wave_barrier();
@@ -453,8 +481,9 @@ void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_fra
     gg.frame0 = frame0;
     DescArgs aa = a;
     aa.n_frames = n_frames;
-    const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * kBlocksPerFrame;
-    hipLaunchKernelGGL(k_describe, dim3(grid), dim3(256), 0, s, gg, aa);
+    static const int bpf = [] { const char* e = getenv("MSLAM_DESC_BPF"); return e ? atoi(e) : kBlocksPerFrame; }();
+    const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)bpf;
+    hipLaunchKernelGGL(k_describe, dim3(grid), dim3(256), 0, s, gg, aa, bpf);
 }
 
 } // namespace mslam
