@@ -22,6 +22,9 @@ namespace mslam
 constexpr int QT = 512;           // threads per workgroup
 constexpr int kLdsKp = 2048;      // levels with at most this many candidates keep ALL working arrays in LDS
 constexpr int kMaxCellsPerLevel = 2048;
+constexpr int kBigNodes = 4096;   // k_quadtree_big: node arrays in LDS up to this many list nodes,
+constexpr int kBigKp = 12288;     //                 keypoint -> node links in LDS up to this many candidates
+constexpr int kBigMinPixels = 400000; // levels with more pixels than this get the k_quadtree_big launch
 constexpr int kMaxInitNodes = 64;
 constexpr int kMaxPasses = 40;
 
@@ -122,15 +125,26 @@ struct LdsStore
     using idx_t = uint16_t;
     using info_t = uint8_t;
     static constexpr bool kLds = true;
+    static constexpr bool kCandCopy = true;  // candidates are gathered into LDS; the global copy is for debug_read
+    static constexpr uint32_t kNodeCap = 0;  // 0: the node arrays hold as many nodes as there are candidates
     static __device__ __forceinline__ void cc_zero(uint32_t* cc, uint32_t pos) { cc[2 * pos] = 0, cc[2 * pos + 1] = 0; }
     static __device__ __forceinline__ void cc_add(uint32_t* cc, uint32_t pos, int c) { atomicAdd(&cc[2 * pos + (c >> 1)], 1u << (16 * (c & 1))); }
     static __device__ __forceinline__ uint32_t cc_get(const uint32_t* cc, uint32_t pos, int c) { return (cc[2 * pos + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu; }
+};
+// Large levels (1280x720 and up: 2 000 - 12 000 candidates): the candidates themselves stay in global memory (read
+// only after the gather), the per-node arrays and the keypoint -> node links are in LDS (152 KB, one workgroup per CU).
+struct BigStore : LdsStore
+{
+    static constexpr bool kCandCopy = false;
+    static constexpr uint32_t kNodeCap = kBigNodes; // more nodes than this: give up, the caller runs GlobalStore
 };
 struct GlobalStore
 {
     using idx_t = uint32_t;
     using info_t = uint32_t;
     static constexpr bool kLds = false;
+    static constexpr bool kCandCopy = false;
+    static constexpr uint32_t kNodeCap = 0;
     static __device__ __forceinline__ void cc_zero(uint32_t* cc, uint32_t pos) { cc[4 * pos] = 0, cc[4 * pos + 1] = 0, cc[4 * pos + 2] = 0, cc[4 * pos + 3] = 0; }
     static __device__ __forceinline__ void cc_add(uint32_t* cc, uint32_t pos, int c) { atomicAdd(&cc[4 * pos + c], 1u); }
     static __device__ __forceinline__ uint32_t cc_get(const uint32_t* cc, uint32_t pos, int c) { return ld_atomic(&cc[4 * pos + c]); }
@@ -139,7 +153,7 @@ struct GlobalStore
 // Everything after the candidate count is known.  Instantiated twice and force-inlined so that, in the
 // LDS instance, every working array is a known LDS object (ds_* instructions instead of flat_*).
 template <class S>
-__device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, const LevelGeom& lv, size_t frame,
+__device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, const LevelGeom& lv, size_t frame,
                                          size_t slot, int tid, uint32_t N, int n_cells, const uint32_t* cell_off,
                                          uint32_t* cand, uint32_t* g_cand, typename S::idx_t* kp_node, uint2* nodes,
                                          uint2* nodes2, typename S::idx_t* ncnt, typename S::idx_t* ncnt2,
@@ -164,7 +178,7 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
         }
         const uint32_t v = ckp[(size_t)lo * kCellCap + (j - cell_off[lo])];
         cand[j] = v;
-        if(S::kLds)
+        if(S::kCandCopy)
             g_cand[j] = v; // the global copy is kept for mslam_hip_debug_read
     }
     __syncthreads(); // cell_off may share storage with arrays written below
@@ -277,6 +291,8 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
         }
         const uint32_t T = D;
         __syncthreads();
+        if(S::kNodeCap != 0 && T + U > S::kNodeCap)
+            return false; // (workgroup-uniform) the next list does not fit the LDS node arrays
         // d. materialise the new list; e. re-point the keypoints.  Both only read what step c wrote
         //    (nbase = scan prefix, ninfo = divide flag + child mask) and T, so they share one phase.
         for(uint32_t pos = tid; pos < n; pos += QT)
@@ -358,9 +374,31 @@ __device__ __forceinline__ void quad_run(const Geometry& g, const QuadArgs& a, c
     }
     if(tid == 0)
         a.sel_cnt[slot] = n;
+    return true;
 }
 
-__global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
+// gather step shared by both kernels: candidate offsets per cell (-> cell_off[0 .. n_cells]), returns N
+__device__ __forceinline__ uint32_t quad_cell_offsets(const uint32_t* ccnt, int n_cells, uint32_t* cell_off, Scan& scan)
+{
+    const int tid = threadIdx.x;
+    uint32_t running = 0;
+    for(int base = 0; base < n_cells; base += QT)
+    {
+        const int i = base + tid;
+        const uint32_t v = i < n_cells ? ccnt[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, scan, tot);
+        if(i < n_cells)
+            cell_off[i] = running + ex;
+        running += tot;
+    }
+    if(tid == 0)
+        cell_off[n_cells] = running;
+    __syncthreads();
+    return running;
+}
+
+__global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a, unsigned big_levels)
 {
     __shared__ Scan scan, scan2;
     // LDS working set of the common case (N <= kLdsKp): 74 KB, so two workgroups share a CU.
@@ -391,21 +429,7 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
     //         row-major order inside each cell (:878-951)
     const int n_cells = lv.n_cells;
     const uint32_t* ccnt = a.cell_cnt + frame * g.n_cells + lv.cell_base;
-    uint32_t running = 0;
-    for(int base = 0; base < n_cells; base += QT)
-    {
-        const int i = base + tid;
-        const uint32_t v = i < n_cells ? ccnt[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan(v, scan, tot);
-        if(i < n_cells)
-            cell_off[i] = running + ex;
-        running += tot;
-    }
-    if(tid == 0)
-        cell_off[n_cells] = running;
-    __syncthreads();
-    const uint32_t N = running;
+    const uint32_t N = quad_cell_offsets(ccnt, n_cells, cell_off, scan);
     if(N > (uint32_t)a.cand_cap)
     {
         if(tid == 0)
@@ -427,6 +451,8 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
     if(N <= (uint32_t)kLdsKp)
         quad_run<LdsStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, l_cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
                            l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, l_cc, l_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
+    else if((big_levels >> level) & 1u)
+        return; // k_quadtree_big, launched right behind this kernel, takes this (level, frame)
     else
         quad_run<GlobalStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, a.kp_node + slot * cap,
                               a.nodes_a + slot * cap, a.nodes_b + slot * cap, a.ncnt_a + slot * cap,
@@ -435,12 +461,84 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a)
                               sh_n);
 }
 
+// Second kernel for the levels of large images: the (level, frame) pairs k_quadtree left alone because they have more
+// than kLdsKp candidates.  Same algorithm (quad_run), node arrays in 152 KB of dynamic LDS; levels that outgrow even
+// that (more than kBigKp candidates, or a list of more than kBigNodes nodes) run with every array in global memory.
+__global__ __launch_bounds__(QT) void k_quadtree_big(Geometry g, QuadArgs a, unsigned big_levels)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t big_lds[];
+    __shared__ Scan scan, scan2;
+    __shared__ uint32_t init_cnt[kMaxInitNodes];
+    __shared__ uint32_t init_pos[kMaxInitNodes];
+    __shared__ uint32_t sh_n;
+    uint2* l_nodes_a = reinterpret_cast<uint2*>(big_lds);
+    uint2* l_nodes_b = l_nodes_a + kBigNodes; // doubles as the cell offset table of step 0
+    uint32_t* l_cc = reinterpret_cast<uint32_t*>(l_nodes_b + kBigNodes);
+    uint16_t* l_kp_node = reinterpret_cast<uint16_t*>(l_cc + 2 * kBigNodes);
+    uint16_t* l_ncnt_a = l_kp_node + kBigKp;
+    uint16_t* l_ncnt_b = l_ncnt_a + kBigNodes;
+    uint16_t* l_nbase = l_ncnt_b + kBigNodes;
+    uint8_t* l_ninfo = reinterpret_cast<uint8_t*>(l_nbase + kBigNodes);
+    static_assert(kBigNodes * sizeof(uint2) >= (kMaxCellsPerLevel + 1) * sizeof(uint32_t), "cell offsets must fit");
+    uint32_t* cell_off = reinterpret_cast<uint32_t*>(l_nodes_b);
+
+    // blockIdx.x counts the set bits of big_levels
+    int level = 0;
+    {
+        unsigned m = big_levels;
+        for(unsigned i = 0; i < blockIdx.x; ++i)
+            m &= m - 1;
+        level = __ffs((int)m) - 1;
+    }
+    const size_t frame = blockIdx.y + g.frame0;
+    const LevelGeom& lv = g.lv[level];
+    const int tid = threadIdx.x;
+    const size_t slot = frame * g.n_levels + level;
+    const size_t cap = (size_t)a.cand_cap;
+    uint32_t* cand = a.cand + slot * cap;
+    uint32_t* sel = a.sel + slot * cap;
+    const int n_cells = lv.n_cells;
+    const uint32_t* ccnt = a.cell_cnt + frame * g.n_cells + lv.cell_base;
+    const uint32_t N = quad_cell_offsets(ccnt, n_cells, cell_off, scan);
+    if(N <= (uint32_t)kLdsKp || N > (uint32_t)a.cand_cap)
+        return; // done (or flagged) by k_quadtree
+    bool done = false;
+    if(N <= (uint32_t)kBigKp)
+        done = quad_run<BigStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
+                                  l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, l_cc, l_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
+    if(!done)
+    {
+        __syncthreads();
+        // the cell offsets were overwritten (they share storage with the node arrays): rebuild them
+        quad_cell_offsets(ccnt, n_cells, cell_off, scan);
+        quad_run<GlobalStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, a.kp_node + slot * cap,
+                              a.nodes_a + slot * cap, a.nodes_b + slot * cap, a.ncnt_a + slot * cap,
+                              a.ncnt_b + slot * cap, a.ninfo + slot * cap, a.best + slot * cap,
+                              a.child_cnt + slot * cap * 4, a.best + slot * cap, sel, scan, scan2, init_cnt, init_pos,
+                              sh_n);
+    }
+}
+
 void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_frames, hipStream_t s)
 {
     dim3 grid(g.n_levels, n_frames);
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT), 0, s, gg, a);
+    unsigned big_levels = 0;
+    for(int l = 0; l < g.n_levels; ++l)
+        if(g.lv[l].w * g.lv[l].h > kBigMinPixels)
+            big_levels |= 1u << l;
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT), 0, s, gg, a, big_levels);
+    if(big_levels != 0)
+    {
+        constexpr size_t lds = (size_t)kBigNodes * (8 + 8 + 8 + 2 + 2 + 2 + 1) + (size_t)kBigKp * 2;
+        static const bool attr = [] {
+            return hipFuncSetAttribute((const void*)k_quadtree_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        }();
+        (void)attr;
+        hipLaunchKernelGGL(k_quadtree_big, dim3((unsigned)__builtin_popcount(big_levels), n_frames), dim3(QT), lds, s, gg, a,
+                           big_levels);
+    }
 }
 
 } // namespace mslam

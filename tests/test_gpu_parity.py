@@ -84,6 +84,36 @@ def test_detect_flat_and_noise_frames(pkg, orc, ctx):
     c.close()
 
 
+def test_quadtree_storage_forms(pkg, orc):
+    """k_quadtree / k_quadtree_big pick where the working arrays of a (level, frame) live from its candidate count N and the
+    length n of its node list: N <= 2048 all in LDS; levels of images above 400 k pixels with N <= 12288: node arrays in
+    LDS (k_quadtree_big), falling back to global memory when the list outgrows 4096 nodes; anything larger in global
+    memory.  One 1280x720 frame per regime (texture / texture with a tiny stop area / noise), compared with the oracle."""
+    import synth
+    tex = synth.make_stream(1, 1280, 720, seed=321)[0]
+    tex_hd = synth.make_stream(1, 1920, 1080, seed=322)[0]
+    noise = np.random.default_rng(6).integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    seen = set()
+    for frame, levels, min_area in [(tex, 4, 1000), (tex_hd, 2, 40), (noise, 2, 300)]:
+        H, W = frame.shape[:2]
+        c = pkg.Context(width=W, height=H, n_levels=levels, min_node_area=min_area, max_keypoints=65535,
+                        max_candidates=262144)
+        got = c.detect(frame, max_out=65535)
+        assert_same_detection(got, orc.detect(frame, orc.params(n_levels=levels, min_size=min_area)))
+        N = c.debug_counts(pkg.DBG_CANDIDATES, 1)[0]
+        n = c.debug_counts(pkg.DBG_SELECTED, 1)[0]
+        for l in range(levels):
+            big_level = round(W / 1.2 ** l) * round(H / 1.2 ** l) > 400000
+            if N[l] <= 2048:
+                seen.add("lds")
+            elif big_level and N[l] <= 12288:
+                seen.add("big" if n[l] <= 4096 else "big-overflow")
+            else:
+                seen.add("global")
+        c.close()
+    assert seen >= {"big", "big-overflow", "global"}, seen
+
+
 def test_capacity_is_loud(pkg, synth_frames):
     c = pkg.Context(width=640, height=480, max_keypoints=100)
     with pytest.raises(pkg.MslamHipError) as e:
@@ -322,7 +352,7 @@ def test_stage_timing_modes_do_not_change_results(pkg, orc, synth_frames):
 
 def test_cfg5_full_hd_three_levels(pkg, orc):
     """BASELINE cfg5: 1920x1080, 3 levels, ~15 k keypoints per frame, detect + ratio-test match of two frames
-    (the level-0 quadtree runs in its global-memory form, the matcher on 15 k x 15 k pairs)"""
+    (the quadtree of every level runs in k_quadtree_big, the matcher on 15 k x 15 k pairs)"""
     import synth
     frames = synth.make_stream(2, 1920, 1080, seed=4321)
     c = pkg.Context(width=1920, height=1080, n_levels=3, min_node_area=150, max_keypoints=32768, max_candidates=131072)
