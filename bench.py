@@ -30,6 +30,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -127,6 +128,9 @@ def parse():
     ap.add_argument("--voc-levels", type=int, default=6, help="vocabulary depth L (k=10): 6 -> 1e6 words")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU run) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras-timeout", type=int, default=300,
+                    help="with several ranks: seconds the legs after the timed region may take before rank 0 prints "
+                         "the line without them")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs after the timed region (popcount matcher, serialized stages, PCIe-inclusive, "
                          "exchange): what the profiling passes use")
@@ -342,7 +346,7 @@ def main():
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         return float(t_max.item()), timed
 
-    dt_max, timed = timed_run(w_eff, True)
+    dt_max, timed_all = timed_run(w_eff, True)
 
     # units processed: keypoints extracted (and matched against the previous frame) in the timed steps
     n_kp = sum(counts_per_batch[(w_eff + i) % n_batches] for i in range(a.steps))
@@ -351,127 +355,8 @@ def main():
         dist.all_reduce(kp_sum, op=dist.ReduceOp.SUM)
     kp_total = float(kp_sum.item())
 
-    # ---- after the timed region ---------------------------------------------------------------------------
-    extras = {}
-    if not a.no_extras:
-        # the same run with the xor/popcount matcher (the form north_star names): both values are always quoted
-        ctx.set_matcher(pkg.MATCHER_POPCOUNT)
-        for i in range(2):
-            step(i)
-        settle()
-        dt_pop, _ = timed_run(w_eff, False)
-        ctx.set_matcher(pkg.MATCHER_AUTO)
-        extras["value_popcount_matcher"] = kp_total / dt_pop
-        extras["ms_per_step_popcount_matcher"] = dt_pop / a.steps * 1e3
-
-        # every stage alone on the GPU (everything serialised on one stream)
-        ctx.set_profiling(1)
-        ser, reps = {}, 5
-        for i in range(reps):
-            step(i)
-            for name, ms in ctx.stage_times():
-                ser[name] = ser.get(name, 0.0) + ms / reps
-        ctx.set_profiling(0)
-        settle()
-        extras["stages_ms_serialized"] = {k: round(x, 4) for k, x in ser.items()}
-
-        if world > 1:
-            # the loop-candidate exchange: BoW vectors of the batch -> ONE all-gather -> cross-stream scores
-            n_ex = max(3, min(10, a.steps))
-            for i in range(2):
-                step(i, bow=False)
-                ctx.bow_batch_dev(True)
-                cross.step_gpu(ctx, ts, B)
-            settle()
-            c0 = cross.collectives
-            t0 = time.perf_counter()
-            for i in range(n_ex):
-                ctx.bow_batch_dev(True)
-                scores = cross.step_gpu(ctx, ts, B)
-            settle()
-            dt_ex = time.perf_counter() - t0
-            t_ex = torch.tensor([dt_ex], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t_ex, op=dist.ReduceOp.MAX)
-            s_host = scores.cpu().numpy()
-            extras["exchange"] = {
-                "what": "per batch: DBoW3 vectors of %d frames (k=10 L=%d vocabulary) -> pack -> ONE "
-                        "all_gather_into_tensor -> L1 scores of own frame t vs frame t of every stream" % (B, a.voc_levels),
-                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                "collectives_per_batch": (cross.collectives - c0) / float(n_ex),
-                "bytes_per_rank_per_batch": 4 * set_dwords(B, cross.k_max),
-                "ms_per_batch_incl_bow": float(t_ex.item()) / n_ex * 1e3,
-                "self_score_min": float(s_host[:, rank].min()),
-                "cross_score_max": float(np.delete(s_host, rank, 1).max())}
-
-        if world == 1 and rank == 0:
-            # PCIe-inclusive: frames + depth start in pinned host memory, double-buffered H2D on a copy stream while
-            # the previous batch is processed; keypoints, descriptors, matches and 3-D points are copied back (D2H)
-            PB = min(250, B)
-            n_pb = 12
-            h_rgb = torch.from_numpy(frames[:PB]).pin_memory()
-            h_dep = torch.from_numpy(np.ascontiguousarray(d_depth[:PB].cpu().numpy())).pin_memory()
-            dbuf = [(torch.empty_like(h_rgb, device="cuda"), torch.empty_like(h_dep, device="cuda")) for _ in range(2)]
-            copy_stream = torch.cuda.Stream()
-            ev_in = [torch.cuda.Event() for _ in range(2)]
-            ev_free = [torch.cuda.Event() for _ in range(2)]
-            K = ctx.params.max_keypoints
-            host_out = {}
-
-            def results_to_host():
-                v, pv = ctx.batch_view(), ctx.points_view()
-                ctx.join_matcher()
-                with torch.cuda.stream(ts):
-                    for name, ptr, shape, dt in (("count", v.count, (PB,), torch.int32), ("xy", v.xy, (PB, K, 2), torch.float32),
-                                                 ("desc", v.desc, (PB, K, 32), torch.uint8),
-                                                 ("angle", v.angle, (PB, K), torch.float32),
-                                                 ("octave", v.octave, (PB, K), torch.int32),
-                                                 ("mfrom", v.match_from, (PB, K), torch.int32),
-                                                 ("mto", v.match_to, (PB, K), torch.int32),
-                                                 ("mcount", v.match_count, (PB,), torch.int32),
-                                                 ("xyz", pv.xyz, (PB, K, 3), torch.float64),
-                                                 ("valid", pv.valid, (PB, K), torch.uint8)):
-                        src = view_as_tensor(ptr, shape, dt)
-                        if name not in host_out:
-                            host_out[name] = torch.empty(shape, dtype=dt).pin_memory()
-                        host_out[name].copy_(src, non_blocking=True)
-
-            def h2d(i):
-                with torch.cuda.stream(copy_stream):
-                    if i >= 2:
-                        copy_stream.wait_event(ev_free[i % 2])  # the batch that used this buffer is done with it
-                    dbuf[i % 2][0].copy_(h_rgb, non_blocking=True)
-                    dbuf[i % 2][1].copy_(h_dep, non_blocking=True)
-                    ev_in[i % 2].record(copy_stream)
-
-            def run_pcie(n):
-                h2d(0)
-                for i in range(n):
-                    if i + 1 < n:
-                        h2d(i + 1)
-                    ts.wait_event(ev_in[i % 2])
-                    ctx.detect_batch_dev(dbuf[i % 2][0].data_ptr(), PB)
-                    ctx.match_batch_dev(0.7, True)
-                    ctx.backproject_batch_dev(dbuf[i % 2][1].view(torch.int16).data_ptr())
-                    ev_free[i % 2].record(ts)
-                    results_to_host()
-                settle()
-
-            run_pcie(2)
-            t0 = time.perf_counter()
-            run_pcie(n_pb)
-            dt_p = time.perf_counter() - t0
-            kp_p = int(host_out["count"].sum()) * n_pb
-            d2h = sum(t.numel() * t.element_size() for t in host_out.values())
-            extras["pcie_inclusive"] = {
-                "frames_per_s": n_pb * PB / dt_p, "keypoints_per_s": kp_p / dt_p,
-                "h2d_GBps": n_pb * (h_rgb.numel() + 2 * h_dep.numel()) / dt_p / 1e9, "d2h_GBps": n_pb * d2h / dt_p / 1e9,
-                "how": "%d batches of %d frames: RGB + depth from pinned host memory by double-buffered async H2D on a "
-                       "copy stream, overlapped with extract + match + back-projection of the previous batch; keypoints, "
-                       "descriptors, matches and 3-D points (capacity-strided arrays) copied back to pinned host memory; "
-                       "the headline `value` is the HBM-resident rate" % (n_pb, PB)}
-
-    out = None
-    if rank == 0:
+    def make_line(extras, with_cpu=True):
+        timed = timed_all
         # per-stage launch durations measured inside the timed region (HIP events on the launching stream);
         # a step's entries end with its last stage; a very long run stops recording at 8192 entries: keep whole steps
         last = "bow_score" if a.bow else "backproject"
@@ -564,13 +449,156 @@ def main():
         if "value_popcount_matcher" in extras:
             extras["popcount_match_kernel"] = POPCOUNT_KERNEL
         out.update(extras)
-        if not a.no_cpu_baseline and world == 1:
+        if with_cpu and not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, dict(n_levels=a.levels, min_size=a.min_area), a.cpu_seconds, cv,
                                                a.n_features)
-    ctx.close()
+        return out
+
+    # ---- after the timed region ---------------------------------------------------------------------------
+    extras = {}
+    # Nothing after the timed region may cost the headline line: a failure in an extra leg is recorded in the line, and
+    # with several ranks a watchdog prints the line without the extras if a collective of the extras never completes
+    # (rank 0) / ends the rank quietly (the others).
+    watchdog = None
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        def give_up():
+            if rank == 0:
+                line = make_line({"extras_error": "the legs after the timed region did not finish within %d s" % a.extras_timeout},
+                                 with_cpu=False)
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(a.extras_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        if not a.no_extras:
+            # the same run with the xor/popcount matcher (the form north_star names): both values are always quoted
+            ctx.set_matcher(pkg.MATCHER_POPCOUNT)
+            for i in range(2):
+                step(i)
+            settle()
+            dt_pop, _ = timed_run(w_eff, False)
+            ctx.set_matcher(pkg.MATCHER_AUTO)
+            extras["value_popcount_matcher"] = kp_total / dt_pop
+            extras["ms_per_step_popcount_matcher"] = dt_pop / a.steps * 1e3
+
+            # every stage alone on the GPU (everything serialised on one stream)
+            ctx.set_profiling(1)
+            ser, reps = {}, 5
+            for i in range(reps):
+                step(i)
+                for name, ms in ctx.stage_times():
+                    ser[name] = ser.get(name, 0.0) + ms / reps
+            ctx.set_profiling(0)
+            settle()
+            extras["stages_ms_serialized"] = {k: round(x, 4) for k, x in ser.items()}
+
+            if world > 1:
+                # the loop-candidate exchange: BoW vectors of the batch -> ONE all-gather -> cross-stream scores
+                n_ex = max(3, min(10, a.steps))
+                for i in range(2):
+                    step(i, bow=False)
+                    ctx.bow_batch_dev(True)
+                    cross.step_gpu(ctx, ts, B)
+                settle()
+                c0 = cross.collectives
+                t0 = time.perf_counter()
+                for i in range(n_ex):
+                    ctx.bow_batch_dev(True)
+                    scores = cross.step_gpu(ctx, ts, B)
+                settle()
+                dt_ex = time.perf_counter() - t0
+                t_ex = torch.tensor([dt_ex], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t_ex, op=dist.ReduceOp.MAX)
+                s_host = scores.cpu().numpy()
+                extras["exchange"] = {
+                    "what": "per batch: DBoW3 vectors of %d frames (k=10 L=%d vocabulary) -> pack -> ONE "
+                            "all_gather_into_tensor -> L1 scores of own frame t vs frame t of every stream" % (B, a.voc_levels),
+                    "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                    "collectives_per_batch": (cross.collectives - c0) / float(n_ex),
+                    "bytes_per_rank_per_batch": 4 * set_dwords(B, cross.k_max),
+                    "ms_per_batch_incl_bow": float(t_ex.item()) / n_ex * 1e3,
+                    "self_score_min": float(s_host[:, rank].min()),
+                    "cross_score_max": float(np.delete(s_host, rank, 1).max())}
+
+            if world == 1 and rank == 0:
+                # PCIe-inclusive: frames + depth start in pinned host memory, double-buffered H2D on a copy stream while
+                # the previous batch is processed; keypoints, descriptors, matches and 3-D points are copied back (D2H)
+                PB = min(250, B)
+                n_pb = 12
+                h_rgb = torch.from_numpy(frames[:PB]).pin_memory()
+                h_dep = torch.from_numpy(np.ascontiguousarray(d_depth[:PB].cpu().numpy())).pin_memory()
+                dbuf = [(torch.empty_like(h_rgb, device="cuda"), torch.empty_like(h_dep, device="cuda")) for _ in range(2)]
+                copy_stream = torch.cuda.Stream()
+                ev_in = [torch.cuda.Event() for _ in range(2)]
+                ev_free = [torch.cuda.Event() for _ in range(2)]
+                K = ctx.params.max_keypoints
+                host_out = {}
+
+                def results_to_host():
+                    v, pv = ctx.batch_view(), ctx.points_view()
+                    ctx.join_matcher()
+                    with torch.cuda.stream(ts):
+                        for name, ptr, shape, dt in (("count", v.count, (PB,), torch.int32), ("xy", v.xy, (PB, K, 2), torch.float32),
+                                                     ("desc", v.desc, (PB, K, 32), torch.uint8),
+                                                     ("angle", v.angle, (PB, K), torch.float32),
+                                                     ("octave", v.octave, (PB, K), torch.int32),
+                                                     ("mfrom", v.match_from, (PB, K), torch.int32),
+                                                     ("mto", v.match_to, (PB, K), torch.int32),
+                                                     ("mcount", v.match_count, (PB,), torch.int32),
+                                                     ("xyz", pv.xyz, (PB, K, 3), torch.float64),
+                                                     ("valid", pv.valid, (PB, K), torch.uint8)):
+                            src = view_as_tensor(ptr, shape, dt)
+                            if name not in host_out:
+                                host_out[name] = torch.empty(shape, dtype=dt).pin_memory()
+                            host_out[name].copy_(src, non_blocking=True)
+
+                def h2d(i):
+                    with torch.cuda.stream(copy_stream):
+                        if i >= 2:
+                            copy_stream.wait_event(ev_free[i % 2])  # the batch that used this buffer is done with it
+                        dbuf[i % 2][0].copy_(h_rgb, non_blocking=True)
+                        dbuf[i % 2][1].copy_(h_dep, non_blocking=True)
+                        ev_in[i % 2].record(copy_stream)
+
+                def run_pcie(n):
+                    h2d(0)
+                    for i in range(n):
+                        if i + 1 < n:
+                            h2d(i + 1)
+                        ts.wait_event(ev_in[i % 2])
+                        ctx.detect_batch_dev(dbuf[i % 2][0].data_ptr(), PB)
+                        ctx.match_batch_dev(0.7, True)
+                        ctx.backproject_batch_dev(dbuf[i % 2][1].view(torch.int16).data_ptr())
+                        ev_free[i % 2].record(ts)
+                        results_to_host()
+                    settle()
+
+                run_pcie(2)
+                t0 = time.perf_counter()
+                run_pcie(n_pb)
+                dt_p = time.perf_counter() - t0
+                kp_p = int(host_out["count"].sum()) * n_pb
+                d2h = sum(t.numel() * t.element_size() for t in host_out.values())
+                extras["pcie_inclusive"] = {
+                    "frames_per_s": n_pb * PB / dt_p, "keypoints_per_s": kp_p / dt_p,
+                    "h2d_GBps": n_pb * (h_rgb.numel() + 2 * h_dep.numel()) / dt_p / 1e9, "d2h_GBps": n_pb * d2h / dt_p / 1e9,
+                    "how": "%d batches of %d frames: RGB + depth from pinned host memory by double-buffered async H2D on a "
+                           "copy stream, overlapped with extract + match + back-projection of the previous batch; keypoints, "
+                           "descriptors, matches and 3-D points (capacity-strided arrays) copied back to pinned host memory; "
+                           "the headline `value` is the HBM-resident rate" % (n_pb, PB)}
+    except Exception as e:  # noqa: BLE001 - any failure of an extra leg must not cost the headline
+        extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
+
+    out = make_line(extras) if rank == 0 else None
+    try:
+        ctx.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        if watchdog is not None:
+            watchdog.cancel()
     if rank == 0:
         print(json.dumps(out))
 
