@@ -810,8 +810,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 StageScope t(c, "fast", cs);
                 // the tiles of a level append to its list with atomics: counts start at zero
                 HIPCHK(c, hipMemsetAsync(c->quad.cand_cnt + (size_t)f0 * g.n_levels, 0, (size_t)nf * g.n_levels * 4, cs));
-                for(int l = 0; l < g.n_levels; ++l)
-                    launch_fast_tiles(c->d_pyr, g, l, c->p.ini_fast_thr, sa, f0, nf, cs);
+                launch_fast_tiles(c->d_pyr, g, c->p.ini_fast_thr, sa, f0, nf, cs);
             }
             {
                 StageScope t(c, "select", cs);

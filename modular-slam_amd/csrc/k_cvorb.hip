@@ -124,20 +124,27 @@ constexpr int kSP = 72; // LDS tile pitch = tile width 64 + 2 * (3 + 1)
 constexpr int kSc = 68; // score-map pitch (66 used)
 
 __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ pyr, Geometry g, int level, int tiles_x,
-                                                    int thr, CvSelectArgs a)
+                                                    int n_tiles, int n_frames, int thr, CvSelectArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[72 * kSP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kSc];
-    __shared__ uint16_t list[66 * 66];
+    __shared__ __attribute__((aligned(4))) uint16_t list[66 * 72 + 2];
+    constexpr uint32_t kDump = 66 * 72; // write-only slot for rejected pixels
     __shared__ uint32_t n_list;
 
+    // XCD-aware mapping (as k_fast_cells): all tiles of a frame get ids with the same (id & 7) and meet in one L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int f_local = (slot / n_tiles) * 8 + xcd;
+    if(f_local >= n_frames)
+        return;
+    const int t_id = slot % n_tiles;
     const LevelGeom& lv = g.lv[level];
     const int w = lv.w, h = lv.h, pitch = lv.pitch;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tx = t_id % tiles_x, ty = t_id / tiles_x;
     const int X0 = tx * 64, Y0 = ty * 64; // the tile's own block; scores cover (X0-1, Y0-1) + 66x66, pixels (X0-4, Y0-4) + 72x72
-    const size_t frame = blockIdx.y + g.frame0;
+    const size_t frame = (size_t)f_local + g.frame0;
     const uint8_t* src = pyr + frame * g.slab + lv.offset;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
 
     for(int i = tid; i < 72 * 18; i += 256) // 72 rows x 18 dwords (4 pixels each)
     {
@@ -156,39 +163,87 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         n_list = 0;
     __syncthreads();
 
-    // compass test over the 66x66 scored region: a 9-arc contains two adjacent compass points of one polarity
-    for(int i = tid; i < 66 * 66; i += 256)
+    // compass test over the 66x66 scored region (a 9-arc contains two adjacent compass points of one polarity), FOUR
+    // pixels per lane as in k_fast_cells: item i = (scored row r, tile dword q); the scored columns are tile columns
+    // 3 .. 68, i.e. byte 3 of dword 0, dwords 1 .. 16 and byte 0 of dword 17.  Items are numbered row-major over the
+    // 18-dword rows, so the five LDS reads of a wave are linear in the lane index.
     {
-        const int ly = i / 66, lx = i - ly * 66;
-        const int x = X0 - 1 + lx, y = Y0 - 1 + ly;
-        bool keep = false;
-        if(x >= 3 && x < w - 3 && y >= 3 && y < h - 3)
+        const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
+        const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
+        // tested tile columns [c_lo, c_hi) and scored rows [r_lo, r_hi): FAST's 3-pixel frame of the level
+        const int c_lo = max(3, 7 - X0), c_hi = min(69, w - 3 - (X0 - 4));
+        const int r_lo = max(0, 4 - Y0), r_hi = min(66, h - 3 - (Y0 - 1));
+        for(int i0 = 0; i0 < 66 * 18; i0 += 256)
         {
-            const uint8_t* p = &tile[(ly + 3) * kSP + lx + 3];
-            const int v = p[0], hi = v + thr, lo = v - thr;
-            const int p0 = p[3 * kSP], p8 = p[-3 * kSP], p4 = p[3], p12 = p[-3];
-            keep = ((p0 > hi || p8 > hi) && (p4 > hi || p12 > hi)) || ((p0 < lo || p8 < lo) && (p4 < lo || p12 < lo));
-        }
-        const unsigned long long m = __ballot(keep);
-        if(m)
-        {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if((tid & 63) == leader)
-                base = atomicAdd(&n_list, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, leader);
-            if(keep)
-                list[base + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
+            const int i = i0 + tid;
+            const int r = (i * 3641) >> 16, q = i - r * 18; // i / 18 for i < 16384
+            uint32_t keep = 0;
+            if(i < 66 * 18 && r >= r_lo && r < r_hi)
+            {
+                const int lo4 = min(max(c_lo - 4 * q, 0), 4), hi4 = min(max(c_hi - 4 * q, 0), 4);
+                const uint32_t m4 = ((1u << hi4) - 1u) & ~((1u << lo4) - 1u);          // pixels j of the quad that are tested
+                const uint32_t colmask = ((m4 * 0x00204081u) & 0x01010101u) << 7;      // as the sign bits of the four bytes
+                const uint32_t* row = T + (r + 3) * 18 + q;
+                const uint32_t L = row[-1], C = row[0], R = row[1];
+                const uint32_t U = row[-3 * 18], D = row[3 * 18];
+                const uint32_t Lf = __builtin_amdgcn_alignbyte(C, L, 1); // columns x-3 of the four pixels
+                const uint32_t Rt = __builtin_amdgcn_alignbyte(R, C, 3); // columns x+3
+                uint32_t k[2];
+#pragma unroll
+                for(int hh = 0; hh < 2; ++hh)
+                {
+                    const uint32_t sel = hh == 0 ? 0x0c010c00u : 0x0c030c02u; // bytes (0,1) or (2,3) as u16 lanes
+                    typedef short s16x2 __attribute__((ext_vector_type(2)));
+                    auto wd = [&](uint32_t v) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, v, sel)); };
+                    const s16x2 t2 = __builtin_bit_cast(s16x2, thr2);
+                    const s16x2 cc = wd(C), hi = cc + t2, lo = cc - t2;
+                    const s16x2 p0 = wd(D), p4 = wd(Rt), p8 = wd(U), p12 = wd(Lf);
+                    const s16x2 mb = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12));
+                    const s16x2 md = __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
+                    k[hh] = __builtin_bit_cast(uint32_t, (s16x2)(hi - mb)) | __builtin_bit_cast(uint32_t, (s16x2)(md - lo));
+                }
+                keep = __builtin_amdgcn_perm(k[1], k[0], 0x07050301u) & colmask;
+            }
+            // compaction: wave-wide inclusive scan of the per-lane counts with DPP adds, one LDS atomic per wave
+            const uint32_t cnt = (uint32_t)__popc(keep);
+            uint32_t inc = cnt;
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true); // row_shr:1
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true); // row_shr:2
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xE, true); // row_shr:4
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xC, true); // row_shr:8
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xA, 0xF, true); // row_bcast:15
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xC, 0xF, true); // row_bcast:31
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if(tot != 0)
+            {
+                uint32_t base = 0;
+                if(lane == 0)
+                    base = atomicAdd(&n_list, tot);
+                base = __builtin_amdgcn_readfirstlane(base);
+                uint32_t pos2 = 2u * (base + inc - cnt); // byte offset into list[]
+                const uint32_t dump2 = 2u * kDump;
+                const uint32_t yx = (uint32_t)(((r + 3) << 8) | (4 * q)); // (tile row, tile column) of the quad's pixel 0
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+                {
+                    const int m = __builtin_amdgcn_sbfe((int)keep, 8 * j + 7, 1); // -1 when kept
+                    uint32_t slot2;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(slot2) : "v"(m), "v"(pos2), "v"(dump2));
+                    *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(list) + slot2) = (uint16_t)(yx + j);
+                    pos2 = (uint32_t)__mul24(m, -2) + pos2;
+                }
+            }
         }
     }
     __syncthreads();
     const uint32_t n = n_list;
     for(uint32_t j = tid; 2 * j < n; j += 256) // two listed pixels per lane (arc_score.hpp)
     {
-        const int ia = list[2 * j], ib = 2 * j + 1 < n ? list[2 * j + 1] : ia;
-        const int ay = ia / 66, ax = ia - ay * 66, by = ib / 66, bx = ib - by * 66;
-        const uint8_t* pa = &tile[(ay + 3) * kSP + ax + 3];
-        const uint8_t* pb = &tile[(by + 3) * kSP + bx + 3];
+        const uint32_t two = *reinterpret_cast<const uint32_t*>(&list[2 * j]);
+        const uint32_t ca = two & 0xFFFFu, cb = 2 * j + 1 < n ? two >> 16 : ca;
+        const int ay = (int)(ca >> 8), ax = (int)(ca & 0xFF), by = (int)(cb >> 8), bx = (int)(cb & 0xFF);
+        const uint8_t* pa = &tile[ay * kSP + ax];
+        const uint8_t* pb = &tile[by * kSP + bx];
         const uint32_t vv = ((uint32_t)pa[0] + kArcBias) | (((uint32_t)pb[0] + kArcBias) << 16);
         uint32_t e[16];
 #define MSLAM_E(k, off) e[k] = vv - ((uint32_t)pa[off] | ((uint32_t)pb[off] << 16))
@@ -212,9 +267,9 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         int sa, sb;
         arc_score2(e, sa, sb);
         if(sa >= thr && sa > 0)
-            sc[ay * kSc + ax] = (uint8_t)sa;
+            sc[(ay - 3) * kSc + (ax - 3)] = (uint8_t)sa;
         if(sb >= thr && sb > 0)
-            sc[by * kSc + bx] = (uint8_t)sb;
+            sc[(by - 3) * kSc + (bx - 3)] = (uint8_t)sb;
     }
     __syncthreads();
     // 3x3 strict NMS over the listed pixels of the tile's own 64x64 block + runByImageBorder(edge)
@@ -229,7 +284,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         if(i < n)
         {
             const int idx = list[i];
-            const int ly = idx / 66, lx = idx - ly * 66;
+            const int ly = (idx >> 8) - 3, lx = (idx & 0xFF) - 3;
             const int x = X0 - 1 + lx, y = Y0 - 1 + ly;
             const uint8_t* q = &sc[ly * kSc + lx];
             const int s = q[0];
@@ -256,35 +311,89 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
     }
 }
 
-void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int level, int thr, const CvSelectArgs& a, int frame0,
-                       int n_frames, hipStream_t s)
+void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int thr, const CvSelectArgs& a, int frame0, int n_frames,
+                       hipStream_t s)
 {
-    const LevelGeom& lv = g.lv[level];
-    const int tiles_x = (lv.w + 63) / 64, tiles_y = (lv.h + 63) / 64;
+    // one launch per level (ONE launch over the tiles of all levels measured slower: 1.75 vs 1.46 ms per 1000 frames)
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_fast_tiles, dim3(tiles_x * tiles_y, n_frames), dim3(256), 0, s, d_pyr, gg, level, tiles_x, thr, a);
+    for(int l = 0; l < g.n_levels; ++l)
+    {
+        const int tiles_x = (g.lv[l].w + 63) / 64, n_tiles = tiles_x * ((g.lv[l].h + 63) / 64);
+        const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)n_tiles;
+        hipLaunchKernelGGL(k_fast_tiles, dim3(grid), dim3(256), 0, s, d_pyr, gg, l, tiles_x, n_tiles, n_frames, thr, a);
+    }
 }
 
 // ---- retainBest(2n) by FAST score -> Harris -> retainBest(n) by Harris: one workgroup per (level, frame) -------
 __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x, int y)
 {
-    // orb.cpp HarrisResponses: blockSize 7, Sobel-like 3x3 gradients, integer sums, float response
-    int a = 0, b = 0, c = 0;
-    for(int i = -3; i <= 3; ++i)
+    // orb.cpp HarrisResponses: blockSize 7, Sobel-like 3x3 gradients, integer sums, float response.
+    // The 9x9 pixels around (x, y) come in as 27 (unaligned) dword loads — rows y-4 .. y+4, bytes x-4 .. x+7 — instead of
+    // ~400 byte loads; the gradients are built separably in registers:
+    //   V[r][c] = p[r-1][c] + 2 p[r][c] + p[r+1][c]  ->  Ix[r][j] = V[r][j+1] - V[r][j-1]
+    //   H[r][c] = p[r][c-1] + 2 p[r][c] + p[r][c+1]  ->  Iy[r][j] = H[r+1][j] - H[r-1][j]
+    // A sliding window of three source rows keeps the register count low: row r+1 arrives, V[r] and H[r+1] follow.
+    const uint8_t* base = img + (size_t)(y - 4) * pitch + (x - 4);
+    struct Raw
     {
-        const uint8_t* r0 = img + (size_t)(y + i - 1) * pitch + x;
-        const uint8_t* r1 = r0 + pitch;
-        const uint8_t* r2 = r1 + pitch;
+        uint32_t d0, d1, d2;
+    };
+    auto load_raw = [&](int r) { // bytes x-4 .. x+7 of row y-4+r
+        const uint8_t* rp = base + (size_t)r * pitch;
+        Raw w;
+        __builtin_memcpy(&w.d0, rp, 4);
+        __builtin_memcpy(&w.d1, rp + 4, 4);
+        __builtin_memcpy(&w.d2, rp + 8, 4);
+        return w;
+    };
+    auto unpack = [&](const Raw& w, int* p) { // p[0..8] = pixels x-4 .. x+4
 #pragma unroll
-        for(int j = -3; j <= 3; ++j)
+        for(int k = 0; k < 4; ++k)
         {
-            const int Ix = (r1[j + 1] - r1[j - 1]) * 2 + (r0[j + 1] - r0[j - 1]) + (r2[j + 1] - r2[j - 1]);
-            const int Iy = (r2[j] - r0[j]) * 2 + (r2[j - 1] - r0[j - 1]) + (r2[j + 1] - r0[j + 1]);
+            p[k] = (int)((w.d0 >> (8 * k)) & 0xFFu);
+            p[4 + k] = (int)((w.d1 >> (8 * k)) & 0xFFu);
+        }
+        p[8] = (int)(w.d2 & 0xFFu);
+    };
+    int pm[9], pc[9], pn[9]; // rows r-1, r, r+1
+    int Hm[7], Hc[7], Hn[7]; // H of rows r-1, r, r+1 (columns j = -3 .. 3 -> index j+3, pixel index j+4)
+    auto hrow = [&](const int* p, int* H) {
+#pragma unroll
+        for(int j = 0; j < 7; ++j)
+            H[j] = p[j] + 2 * p[j + 1] + p[j + 2];
+    };
+    unpack(load_raw(0), pm);
+    unpack(load_raw(1), pc);
+    hrow(pm, Hm);
+    hrow(pc, Hc);
+    int a = 0, b = 0, c = 0;
+    Raw nxt = load_raw(2);
+    // a ROLLED loop with the next row's three dwords requested one iteration ahead: fully unrolled, the scheduler hoists
+    // all 27 loads and unpacks them at once (235 VGPRs, 2 waves per SIMD, slower than the byte-load version)
+#pragma unroll 1
+    for(int r = 1; r <= 7; ++r) // window row i = r - 4 = -3 .. 3
+    {
+        const Raw cur = nxt;
+        nxt = load_raw(min(r + 2, 8));
+        unpack(cur, pn);
+        hrow(pn, Hn);
+#pragma unroll
+        for(int j = 0; j < 7; ++j)
+        {
+            // pixel index of column j-3 is j+1; V at columns (j-3)+1 and (j-3)-1 -> pixel indices j+2 and j
+            const int Vr = pm[j + 2] + 2 * pc[j + 2] + pn[j + 2], Vl = pm[j] + 2 * pc[j] + pn[j];
+            const int Ix = Vr - Vl, Iy = Hn[j] - Hm[j];
             a += Ix * Ix;
             b += Iy * Iy;
             c += Ix * Iy;
         }
+#pragma unroll
+        for(int k = 0; k < 9; ++k)
+            pm[k] = pc[k], pc[k] = pn[k];
+#pragma unroll
+        for(int k = 0; k < 7; ++k)
+            Hm[k] = Hc[k], Hc[k] = Hn[k];
     }
     const float harris_k = 0.04f;
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
@@ -295,52 +404,39 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x,
     return __fmul_rn(v, s4);
 }
 
-__global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ pyr, Geometry g, CvSelectArgs a)
+// The body of k_cv_select on one (level, frame): `keys` holds the level's n keypoints (any order) and is sorted in place,
+// `kept` / `resp` receive the survivors of the first retainBest and their Harris responses (kept may alias keys: the
+// compaction only writes positions it has already read).  Force-inlined into two callers so that in the common case
+// every array is a known LDS object.
+__device__ __forceinline__ void cv_select_run(uint32_t* keys, uint32_t* kept, float* resp, int n, int quota, const uint8_t* img,
+                                              int pitch, uint32_t* sel, float* sresp, uint32_t* sel_cnt, uint32_t* hist,
+                                              uint32_t* wsum, int& s_thr, uint32_t* sorted_out)
 {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t wsum[4];
-    __shared__ int s_thr;
-    const int level = blockIdx.x;
-    const size_t frame = blockIdx.y + g.frame0;
-    const LevelGeom& lv = g.lv[level];
-    const size_t slot = frame * g.n_levels + level;
-    const uint32_t* cand = a.cand + slot * (size_t)a.cand_cap;
-    uint32_t* kept = a.tmp_kp + slot * (size_t)a.cand_cap;   // after the first retainBest
-    float* kresp = a.tmp_resp + slot * (size_t)a.cand_cap;   // their Harris responses
-    uint32_t* sel = a.sel + slot * (size_t)a.cand_cap;
-    float* sresp = a.sel_resp + slot * (size_t)a.cand_cap;
-    const uint8_t* img = pyr + frame * g.slab + lv.offset;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_raw = (int)a.cand_cnt[slot];
-    if(n_raw > a.cand_cap && tid == 0)
-        atomicOr(a.flags, kFlagCandOverflow);
-    const int n = min(n_raw, a.cand_cap);
-    const int quota = a.quota[level];
     // The tile kernel appended the level's keypoints in arrival order; FAST's own order — the order everything
-    // downstream is defined in — is raster (y, then x), which is ascending order of the packed words.  Bitonic sort
-    // in place (global memory, visible inside the workgroup after a barrier; a level has ~10^3 keypoints).
+    // downstream is defined in — is raster (y, then x), which is ascending order of the packed words: bitonic sort.
     {
-        uint32_t* keys = a.cand + slot * (size_t)a.cand_cap;
         int np2 = 1;
         while(np2 < n)
             np2 <<= 1;
         // normalised bitonic network (every comparator ascending; the first step of a merge mirrors the upper half), so a
         // length that is not a power of two only needs comparators reaching beyond n to be skipped
-        for(int size = 2; size <= np2; size <<= 1)
-            for(int stride = size >> 1; stride > 0; stride >>= 1)
+        for(int lsize = 1; (1 << lsize) <= np2; ++lsize)
+            for(int ls = lsize - 1; ls >= 0; --ls) // stride = 1 << ls: shifts and masks, no integer division
             {
+                const int stride = 1 << ls, size = 1 << lsize;
                 for(int t = tid; t < (np2 >> 1); t += 256)
                 {
+                    const int grp = t >> ls, off = t & (stride - 1);
                     int lo, hi;
-                    if(stride == (size >> 1))
+                    if(ls == lsize - 1)
                     {
-                        const int grp = t / stride, off = t - grp * stride;
-                        lo = grp * size + off;
-                        hi = grp * size + size - 1 - off;
+                        lo = (grp << lsize) + off;
+                        hi = (grp << lsize) + size - 1 - off;
                     }
                     else
                     {
-                        lo = (t / stride) * stride * 2 + (t % stride);
+                        lo = (grp << (ls + 1)) + off;
                         hi = lo + stride;
                     }
                     if(hi < n)
@@ -356,13 +452,19 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
                 __syncthreads();
             }
     }
-    // ordered compaction of a predicate over [0, count): returns the total; `emit(i, pos)` stores element i
-    auto compact = [&](int count, auto&& pred, auto&& emit) -> int {
+    // the level's list in FAST order stays readable in global memory (mslam_hip_debug_read) when it was sorted elsewhere
+    if(sorted_out != nullptr)
+        for(int i = tid; i < n; i += 256)
+            sorted_out[i] = keys[i];
+    // ordered compaction over [0, count): `pred(i, v)` sees element i's value v = load(i), read BEFORE any store of the
+    // same round, so the destination may alias the source; `emit(i, v, pos)` stores it.  Returns the total.
+    auto compact = [&](int count, auto&& load, auto&& pred, auto&& emit) -> int {
         uint32_t running = 0;
         for(int base = 0; base < count; base += 256)
         {
             const int i = base + tid;
-            const bool ok = i < count && pred(i);
+            const uint32_t v = i < count ? load(i) : 0u;
+            const bool ok = i < count && pred(i, v);
             const unsigned long long m = __ballot(ok);
             if(lane == 0)
                 wsum[wave] = (uint32_t)__popcll(m);
@@ -374,7 +476,7 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
                 tot += wsum[k];
             }
             if(ok)
-                emit(i, running + pre + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+                emit(i, v, running + pre + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
             running += tot;
             __syncthreads();
         }
@@ -388,7 +490,7 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
         hist[tid] = 0;
         __syncthreads();
         for(int i = tid; i < n; i += 256)
-            atomicAdd(&hist[kp_score(cand[i])], 1u);
+            atomicAdd(&hist[kp_score(keys[i])], 1u);
         __syncthreads();
         if(tid == 0)
         {
@@ -405,38 +507,75 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
         thr = s_thr;
     }
     const int m1 = compact(
-        n, [&](int i) { return kp_score(cand[i]) >= thr; }, [&](int i, uint32_t pos) { kept[pos] = cand[i]; });
+        n, [&](int i) { return keys[i]; }, [&](int, uint32_t v) { return kp_score(v) >= thr; },
+        [&](int, uint32_t v, uint32_t pos) { kept[pos] = v; });
     __syncthreads();
     // 2. Harris responses (the writes above are visible to the whole workgroup after the barrier)
     for(int i = tid; i < m1; i += 256)
     {
         const uint32_t p = kept[i];
-        kresp[i] = harris_at(img, lv.pitch, kp_x(p), kp_y(p));
+        resp[i] = harris_at(img, pitch, kp_x(p), kp_y(p));
     }
     __syncthreads();
     // 3. retainBest(quota) by Harris: keep iff fewer than `quota` responses are strictly greater (= response >= the
     //    quota-th largest; ties kept)
     const int m2 = compact(
-        m1,
-        [&](int i) {
+        m1, [&](int i) { return kept[i]; },
+        [&](int i, uint32_t) {
             if(m1 <= quota)
                 return true;
             if(quota == 0)
                 return false;
-            const float r = kresp[i];
+            const float r = resp[i];
             int greater = 0;
             for(int j = 0; j < m1; ++j)
-                greater += kresp[j] > r ? 1 : 0;
+                greater += resp[j] > r ? 1 : 0;
             return greater < quota;
         },
-        [&](int i, uint32_t pos) {
-            const uint32_t p = kept[i];
+        [&](int i, uint32_t p, uint32_t pos) {
             // k_describe takes coordinates relative to the (19, 19) origin of the in-tree detector's lists
             sel[pos] = pack_kp(kp_x(p) - kBorder, kp_y(p) - kBorder, kp_score(p));
-            sresp[pos] = kresp[i];
+            sresp[pos] = resp[i];
         });
     if(tid == 0)
-        a.sel_cnt[slot] = (uint32_t)m2;
+        *sel_cnt = (uint32_t)m2;
+}
+
+constexpr int kSelLds = 4096; // levels with at most this many FAST keypoints are selected entirely in LDS
+
+__global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ pyr, Geometry g, CvSelectArgs a)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wsum[4];
+    __shared__ int s_thr;
+    __shared__ uint32_t l_keys[kSelLds];
+    __shared__ float l_resp[kSelLds];
+    const int level = blockIdx.x;
+    const size_t frame = blockIdx.y + g.frame0;
+    const LevelGeom& lv = g.lv[level];
+    const size_t slot = frame * g.n_levels + level;
+    uint32_t* cand = a.cand + slot * (size_t)a.cand_cap;
+    uint32_t* sel = a.sel + slot * (size_t)a.cand_cap;
+    float* sresp = a.sel_resp + slot * (size_t)a.cand_cap;
+    const uint8_t* img = pyr + frame * g.slab + lv.offset;
+    const int tid = threadIdx.x;
+    const int n_raw = (int)a.cand_cnt[slot];
+    if(n_raw > a.cand_cap && tid == 0)
+        atomicOr(a.flags, kFlagCandOverflow);
+    const int n = min(n_raw, a.cand_cap);
+    const int quota = a.quota[level];
+    if(n <= kSelLds)
+    {
+        for(int i = tid; i < n; i += 256)
+            l_keys[i] = cand[i];
+        __syncthreads();
+        // a sort stage is a barrier + LDS traffic here; on the global arrays it was a round trip to L2 (55 stages for
+        // 1024 keypoints: the whole kernel ran at ~250 us per workgroup)
+        cv_select_run(l_keys, l_keys, l_resp, n, quota, img, lv.pitch, sel, sresp, a.sel_cnt + slot, hist, wsum, s_thr, cand);
+    }
+    else
+        cv_select_run(cand, a.tmp_kp + slot * (size_t)a.cand_cap, a.tmp_resp + slot * (size_t)a.cand_cap, n, quota, img,
+                      lv.pitch, sel, sresp, a.sel_cnt + slot, hist, wsum, s_thr, nullptr);
 }
 
 void launch_cv_select(const uint8_t* d_pyr, const Geometry& g, const CvSelectArgs& a, int frame0, int n_frames,
