@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md, matrix cores)
-STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "mslam::k_resize_col", "fast": "mslam::k_fast_cells",
+STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "void mslam::k_resize_col<false>", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur", "describe": "mslam::k_describe",
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
                 "backproject": "mslam::k_backproject"}
@@ -283,7 +283,7 @@ def main():
     ts = torch.cuda.Stream()  # the context's stream is a torch stream: torch copies / collectives order against it
     cv = a.detector == "cvorb"
     if cv:
-        STAGE_KERNEL.update({"resize": "mslam::k_resize_exact", "fast": "mslam::k_fast_score", "select": "mslam::k_cv_select"})
+        STAGE_KERNEL.update({"resize": "void mslam::k_resize_col<true>", "fast": "mslam::k_fast_tiles", "select": "mslam::k_cv_select"})
     ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=a.min_area,
                       max_keypoints=min(32736, max(4096 * k_scale, 2 * a.n_features if cv else 0)),  # 32736: the matrix-core matcher's train range
                       max_candidates=16384 * area, device=dev, stream=ts.cuda_stream,

@@ -450,6 +450,52 @@ static void select_set(mslam_hip_ctx* c, int k)
     c->d_mfrom = o.mfrom, c->d_mto = o.mto, c->d_mcount = o.mcount;
 }
 
+// Quad table of one level for k_resize_col (both interpolation flavours): every 4 destination pixels share one aligned
+// 12-byte source window; per quad {window byte offset, upper-pair flags, 4 v_perm selectors, 4 packed weight pairs}.
+// (The last quad's window may run up to 8 bytes past its row: into the next row, or into the >= 256 bytes of padding
+// behind every level of the slab.)  Leaves `start` at SIZE_MAX when a quad does not fit the window (very large scale factors) or the batch is beyond the
+// kernel's exact index split.
+static void build_quad_table(const std::vector<int32_t>& ofs, const std::vector<uint32_t>& coef, size_t x0, int dw,
+                             int max_batch, std::vector<uint4>& qt, size_t& start_out, int& need_out)
+{
+    const int nq = (dw + 3) / 4;
+    const size_t start = qt.size() / 3;
+    bool ok = true;
+    int need = 0;
+    for(int q = 0; q < nq && ok; ++q)
+    {
+        const int first = ofs[x0 + 4 * q];
+        const uint32_t base = (uint32_t)first & ~3u;
+        uint32_t sel[4], cf[4], flags = 0;
+        for(int k = 0; k < 4; ++k)
+        {
+            const int dx = std::min(4 * q + k, dw - 1);
+            const int shift = ofs[x0 + dx] - (int)base;
+            const uint32_t a0 = coef[x0 + dx] & 0xFFFF, a1 = coef[x0 + dx] >> 16;
+            if(shift < 0 || shift > 10 || a0 > 0xFFF || a1 > 0xFFF)
+                ok = false;
+            // bytes shift, shift+1 of the 12-byte window: in dwords (0,1) when shift <= 6, else in (1,2)
+            const int upper = shift > 6 ? 1 : 0;
+            flags |= (uint32_t)upper << k;
+            // selector bytes [i0, zero, i0+1, zero]: the pair lands as two u16 lanes
+            sel[k] = 0x0c010c00u + (uint32_t)(shift - 4 * upper) * 0x00010001u;
+            cf[k] = a0 | (a1 << 16);
+        }
+        need |= (int)flags;
+        qt.push_back(make_uint4(base, flags, sel[0], sel[1]));
+        qt.push_back(make_uint4(sel[2], sel[3], cf[0], cf[1]));
+        qt.push_back(make_uint4(cf[2], cf[3], 0, 0));
+    }
+    if(!ok || (size_t)max_batch * nq >= (1u << 22)) // (beyond the exact range of the kernel's float index split)
+    {
+        qt.resize(start * 3);
+        start_out = SIZE_MAX;
+        return;
+    }
+    start_out = start;
+    need_out = need;
+}
+
 static int create_impl(mslam_hip_ctx* c)
 {
     const mslam_hip_params& p = c->p;
@@ -542,6 +588,18 @@ static int create_impl(mslam_hip_ctx* c)
             }
             c->cv_window12[l] = ok ? 1 : 0;
         }
+        // the column-walking kernel of the in-tree detector serves INTER_LINEAR_EXACT too (k_resize_col<true>); levels
+        // whose quads do not fit its 12-byte window fall back to k_resize_exact
+        {
+            std::vector<uint4> qt;
+            c->rs_q.assign(p.n_levels, SIZE_MAX);
+            c->rs_need.assign(p.n_levels, 0);
+            for(int l = 1; l < p.n_levels; ++l)
+                build_quad_table(ofs, coef, c->cv_x[l], g.lv[l].w, p.max_batch, qt, c->rs_q[l], c->rs_need[l]);
+            qt.push_back(make_uint4(0, 0, 0, 0));
+            HIPCHK(c, dmalloc(c->d_rs_qt, qt.size()));
+            HIPCHK(c, hipMemcpy(c->d_rs_qt, qt.data(), qt.size() * 16, hipMemcpyHostToDevice));
+        }
         ofs.push_back(0);
         coef.push_back(0);
         HIPCHK(c, dmalloc(c->d_cv_ofs, ofs.size()));
@@ -570,48 +628,7 @@ static int create_impl(mslam_hip_ctx* c)
         c->rs_q.assign(p.n_levels, SIZE_MAX);
         c->rs_need.assign(p.n_levels, 0);
         for(int l = 1; l < p.n_levels; ++l)
-        {
-            const int dw = g.lv[l].w, nq = (dw + 3) / 4;
-            const size_t x0 = c->rs_x[l], start = qt.size() / 3;
-            bool ok = true;
-            int need = 0;
-            for(int q = 0; q < nq && ok; ++q)
-            {
-                const int first = ofs[x0 + 4 * q];
-                const uint32_t base = (uint32_t)first & ~3u;
-                uint32_t sel[4], cf[4], flags = 0;
-                for(int k = 0; k < 4; ++k)
-                {
-                    const int dx = std::min(4 * q + k, dw - 1);
-                    const int shift = ofs[x0 + dx] - (int)base;
-                    const uint32_t a0 = coef[x0 + dx] & 0xFFFF, a1 = coef[x0 + dx] >> 16;
-                    if(shift < 0 || shift > 10 || a0 > 0xFFF || a1 > 0xFFF)
-                        ok = false;
-                    // bytes shift, shift+1 of the 12-byte window: in dwords (0,1) when shift <= 6, else in (1,2)
-                    const int upper = shift > 6 ? 1 : 0;
-                    flags |= (uint32_t)upper << k;
-                    // selector bytes [i0, zero, i0+1, zero]: the pair lands as two u16 lanes
-                    sel[k] = 0x0c010c00u + (uint32_t)(shift - 4 * upper) * 0x00010001u;
-                    cf[k] = a0 | (a1 << 16);
-                }
-                need |= (int)flags;
-                qt.push_back(make_uint4(base, flags, sel[0], sel[1]));
-                qt.push_back(make_uint4(sel[2], sel[3], cf[0], cf[1]));
-                qt.push_back(make_uint4(cf[2], cf[3], 0, 0));
-            }
-            if(!ok)
-            {
-                qt.resize(start * 3);
-                continue;
-            }
-            if((size_t)p.max_batch * nq >= (1u << 22))
-            {
-                qt.resize(start * 3); // beyond the exact range of the kernel's float index split: generic kernel
-                continue;
-            }
-            c->rs_q[l] = start;
-            c->rs_need[l] = need;
-        }
+            build_quad_table(ofs, coef, c->rs_x[l], g.lv[l].w, p.max_batch, qt, c->rs_q[l], c->rs_need[l]);
         qt.push_back(make_uint4(0, 0, 0, 0));
         HIPCHK(c, dmalloc(c->d_rs_qt, qt.size()));
         HIPCHK(c, hipMemcpy(c->d_rs_qt, qt.data(), qt.size() * 16, hipMemcpyHostToDevice));
@@ -781,6 +798,25 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 for(int l = 1; l < g.n_levels; ++l)
                 {
                     const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
+                    if(c->rs_q[l] != SIZE_MAX)
+                    {
+                        ResizeColArgs ca{};
+                        ca.pyr = c->d_pyr;
+                        ca.slab = g.slab;
+                        ca.src_off = sl.offset, ca.sh = sl.h, ca.spitch = sl.pitch;
+                        ca.dst_off = dl.offset, ca.dw = dl.w, ca.dh = dl.h, ca.dpitch = dl.pitch;
+                        ca.qt = c->d_rs_qt + 3 * c->rs_q[l];
+                        ca.yofs = c->d_cv_ofs + c->cv_y[l];
+                        ca.ycoef = c->d_cv_coef + c->cv_y[l];
+                        ca.frame0 = f0, ca.n_frames = nf;
+                        ca.quads = (dl.w + 3) / 4;
+                        ca.inv_quads = 1.0f / (float)ca.quads;
+                        ca.R = 8;
+                        ca.need_mask = c->rs_need[l];
+                        ca.exact = 1;
+                        launch_resize_col(ca, cs);
+                        continue;
+                    }
                     ExactResizeArgs ra{};
                     ra.pyr = c->d_pyr;
                     ra.slab = g.slab;

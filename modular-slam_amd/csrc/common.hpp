@@ -85,6 +85,7 @@ struct ResizeColArgs
     float inv_quads;
     int R;         // destination rows per lane
     int need_mask; // bit k: pixel k of some quad takes its pair from dwords (1,2)
+    int exact;     // 0: INTER_LINEAR (11-bit weights, cv::resize's two-step rounding); 1: INTER_LINEAR_EXACT (8.8 weights)
 };
 void launch_resize_col(const ResizeColArgs& a, hipStream_t s);
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,

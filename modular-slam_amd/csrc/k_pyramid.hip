@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, unsig
 //     (>> 4) of the last two source rows stay in registers: at scale 1.2 a destination row re-uses the lower
 //     source row of the previous one 4 times out of 5, so 1.2 source rows are interpolated per row, not 2;
 //   vertical (VResizeLinear): two 24-bit multiplies per pixel, one dword store per quad.
+// EXACT = INTER_LINEAR_EXACT (the cv::ORB detector mode's pyramid, k_cvorb.hip): the same walk with 8.8 weights,
+//   h = c0 S[o] + c1 S[o+1] (u16, exact), out = (b0 h0 + b1 h1 + 2^15) >> 16; the host tables fold its edge rules in.
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_resize_col(ResizeColArgs a)
 {
     // the block's row table lives in lane registers (lane i: destination row R0 + i, R <= 64) and is read with
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k_resize_col(ResizeColArgs a)
             pv.y = (unsigned short)(pr >> 16);
             cv.x = (unsigned short)(coef[k] & 0xFFFF);
             cv.y = (unsigned short)(coef[k] >> 16);
-            r.h[k] = __builtin_amdgcn_udot2(pv, cv, 0u, false) >> 4;
+            r.h[k] = EXACT ? __builtin_amdgcn_udot2(pv, cv, 0u, false) : __builtin_amdgcn_udot2(pv, cv, 0u, false) >> 4;
         }
         return r;
     };
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(256) void k_resize_col(ResizeColArgs a)
             for(int k = 0; k < 4; ++k)
             {
                 // both factors are below 2^24 (weights <= 2048, h <= 32640): 24-bit multiplies are full rate
-                const uint32_t v = ((__umul24(b0, h0.h[k]) >> 16) + (__umul24(b1, h_cur.h[k]) >> 16) + 2) >> 2; // <= 255
+                // EXACT: h <= 65280, weights <= 256: the products stay below 2^24 as well
+                const uint32_t v = EXACT ? (__umul24(b0, h0.h[k]) + __umul24(b1, h_cur.h[k]) + 32768u) >> 16
+                                         : ((__umul24(b0, h0.h[k]) >> 16) + (__umul24(b1, h_cur.h[k]) >> 16) + 2) >> 2; // <= 255
                 out |= v << (8 * k);
             }
             if(live)
@@ -238,7 +243,10 @@ void launch_resize_col(const ResizeColArgs& args, hipStream_t s)
     // the float reciprocal reproduces idx / quads exactly: (idx + 0.5) / quads is at least 0.5 / quads away from
     // an integer, far more than the rounding error for idx < 2^22 (api.hip checks frames x quads)
     dim3 grid((args.n_frames * args.quads + 255) / 256, (args.dh + args.R - 1) / args.R);
-    hipLaunchKernelGGL(k_resize_col, grid, dim3(256), 0, s, args);
+    if(args.exact)
+        hipLaunchKernelGGL(k_resize_col<true>, grid, dim3(256), 0, s, args);
+    else
+        hipLaunchKernelGGL(k_resize_col<false>, grid, dim3(256), 0, s, args);
 }
 
 void launch_resize(uint8_t* d_pyr, const Geometry& g, int level, const int32_t* d_xofs, const uint32_t* d_xcoef,

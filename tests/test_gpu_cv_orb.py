@@ -47,7 +47,9 @@ def test_cv_orb_detect_parity(orc, cctx, bundled_frames, synth_frames):
 
 @pytest.mark.parametrize("W,H,n,levels,scale,thr,edge", [
     (320, 240, 500, 4, 1.2, 20, 31), (800, 600, 3000, 8, 1.2, 10, 31), (641, 479, 300, 3, 1.5, 25, 25),
-    (1280, 720, 2000, 8, 1.2, 20, 31), (400, 300, 0, 2, 1.2, 20, 31)])
+    (1280, 720, 2000, 8, 1.2, 20, 31), (400, 300, 0, 2, 1.2, 20, 31),
+    # scale factors whose quads outgrow the 12-byte source window of k_resize_col<true>: k_resize_exact, both forms
+    (512, 384, 400, 3, 2.0, 20, 31), (600, 450, 300, 3, 2.7, 20, 31)])
 def test_cv_orb_parameters(pkg, orc, W, H, n, levels, scale, thr, edge):
     import synth
     f = synth.make_stream(1, W, H, seed=W + n)[0]
