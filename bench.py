@@ -380,12 +380,17 @@ def main():
         achieved = bytes_per_launch / (avg[dom] * 1e-3) / 1e9
         kern = STAGE_KERNEL.get(dom, dom)
         traffic, traffic_note = pmc_traffic(kern, 7 if dom == "resize" else 1, fpl)
-        vfrac = valu_fraction(kern, avg[dom], fpl)
+        # the kernel's own duration: alone on the GPU when the serialized pass ran (in place it shares the GPU with
+        # the sibling chunk's kernels, which would halve the fraction)
+        ser = extras.get("stages_ms_serialized", {})
+        alone_ms = ser[dom] / per_step[dom] if dom in ser else None
+        vfrac = valu_fraction(kern, alone_ms if alone_ms else avg[dom], fpl)
         roofline = {"kernel": kern, "stage": dom, "bound": "hbm", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_note,
-                    "limiter": ("vector-ALU issue: %.0f %% of the kernel's duration (SQ_INSTS_VALU, %s)" % (
-                        100 * vfrac, os.path.basename(SQ_PROFILE))) if vfrac is not None else
+                    "limiter": ("vector-ALU issue: %.0f %% of the kernel's duration %s (SQ_INSTS_VALU x 4 cycles, %s)" % (
+                        100 * vfrac, "alone on the GPU" if alone_ms else "in place", os.path.basename(SQ_PROFILE)))
+                    if vfrac is not None else
                                "not HBM (see DESIGN.md §4: every stage but gray is issue- or latency-bound)",
                     "launches_per_step": per_step[dom], "frames_per_launch": fpl, "avg_ms": round(avg[dom], 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
