@@ -845,7 +845,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             {
                 StageScope t(c, "fast", cs);
                 // the tiles of a level append to its list with atomics: counts start at zero
-                HIPCHK(c, hipMemsetAsync(c->quad.cand_cnt + (size_t)f0 * g.n_levels, 0, (size_t)nf * g.n_levels * 4, cs));
+                launch_zero_u32(c->quad.cand_cnt + (size_t)f0 * g.n_levels, nf * g.n_levels, cs);
                 launch_fast_tiles(c->d_pyr, g, c->p.ini_fast_thr, sa, f0, nf, cs);
             }
             {

@@ -167,6 +167,7 @@ struct CvSelectArgs
     int edge;           // edgeThreshold (31)
     int quota[kMaxLevels]; // nfeaturesPerLevel
 };
+void launch_zero_u32(uint32_t* p, int n, hipStream_t s);
 void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int thr, const CvSelectArgs& a, int frame0, int n_frames,
                        hipStream_t s);
 void launch_cv_select(const uint8_t* d_pyr, const Geometry& g, const CvSelectArgs& a, int frame0, int n_frames,

@@ -311,6 +311,21 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
     }
 }
 
+// the per-level counters k_fast_tiles appends to.  A kernel, not hipMemsetAsync: the single-frame path replays this
+// sequence from a HIP graph, and the memset node of a captured hipMemsetAsync was seen to write stale data on replay
+// (ROCm 7.2: the counters came back holding pointer-like garbage once other contexts had run in between).
+__global__ void k_zero_u32(uint32_t* p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i < n)
+        p[i] = 0u;
+}
+void launch_zero_u32(uint32_t* p, int n, hipStream_t s)
+{
+    if(n > 0)
+        hipLaunchKernelGGL(k_zero_u32, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+}
+
 void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int thr, const CvSelectArgs& a, int frame0, int n_frames,
                        hipStream_t s)
 {

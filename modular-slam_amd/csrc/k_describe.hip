@@ -76,8 +76,8 @@ __device__ __forceinline__ float util_sin(float v)
 
 constexpr int kPatchR = 18;               // the rotated pattern reaches |18| (its radius is 18.38; the reference keeps a 19-px border)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
-constexpr int kPatchDw = 16;              // 64 bytes from a 16-byte aligned start cover the 39 needed ones
-constexpr int kPatchBufs = 4;            // LDS patch ring per wave: one being sampled, three in flight (2 / 3 / 4 / 5 / 6 slots: 0.59 / 0.56 / 0.55 / 0.57 / 0.68 ms per 500 frames)
+constexpr int kPatchDw = 12;              // 48-byte rows: 37 needed bytes from a 16-byte aligned start, or from 12 bytes past one
+constexpr int kPatchBufs = 4;            // LDS patch ring per wave: one being sampled, three in flight (3 / 4 / 5 slots of 1776 bytes: 0.505 / 0.493 / 0.486 ms per 500 frames; 28 KB per workgroup, 5 workgroups per CU)
 constexpr int kBlocksPerFrame = 32;
 
 // 64-lane integer sum with DPP adds (VALU only, no LDS crossbar); the total lands in lane 63
@@ -324,33 +324,21 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
         auto dma_patch = [&](int k, int buf) {
             const uint8_t* bsrc = blur + bc(my_poff, k);
             const uint32_t pitch = bc(my_pitch, k);
-            // the 37 needed bytes of a row start `sh` bytes into its first 16-byte chunk: three chunks cover them when
-            // sh <= 11 (3 keypoints out of 4) — 111 lanes = TWO DMA instructions, rows packed at a 48-byte pitch;
-            // otherwise four chunks per row, 148 lanes = three instructions, 64-byte pitch, chunks XOR-swizzled by row
-            if((bc(my_sh, k) >> 4) <= 11u)
-            {
+            // the 37 needed bytes of a row start `sh` bytes into its first 16-byte chunk;
+            // three 16-byte chunks per row: 111 lanes = TWO DMA instructions, rows packed at a 48-byte pitch.  When sh > 11
+            // the chunks start 12 bytes past the aligned one (bytes [12, 60) of the row's 64-byte span hold the 37 needed
+            // ones): LDS-DMA b128 only needs a 4-byte aligned global address.  (A 12-byte DMA would not do: b96 writes its
+            // 12 bytes at a 16-byte lane stride in LDS.)
+            bsrc += (bc(my_sh, k) >> 4) > 11u ? 12 : 0;
 #pragma unroll
-                for(int q = 0; q < 2; ++q)
-                {
-                    const uint32_t t = (uint32_t)lane + 64u * q;
-                    const uint32_t row = (t * 21846u) >> 16; // t / 3
-                    if(t < (uint32_t)(kPatchRows * 3))
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(bsrc + __umul24(row, pitch) + 16u * (t - 3u * row)),
-                            (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
-                }
-            }
-            else
+            for(int q = 0; q < 2; ++q)
             {
-#pragma unroll
-                for(int q = 0; q < 3; ++q)
-                {
-                    const uint32_t t = (uint32_t)lane + 64u * q;
-                    if(t < (uint32_t)(kPatchRows * 4))
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(bsrc + __umul24(t >> 2, pitch) + 16u * ((t & 3u) ^ ((t >> 3) & 3u))),
-                            (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
-                }
+                const uint32_t t = (uint32_t)lane + 64u * q;
+                const uint32_t row = (t * 21846u) >> 16; // t / 3
+                if(t < (uint32_t)(kPatchRows * 3))
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(bsrc + __umul24(row, pitch) + 16u * (t - 3u * row)),
+                        (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
             }
         };
         constexpr int kDepth = kPatchBufs - 1; // patches in flight beside the one being sampled
@@ -405,9 +393,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 const f32x2 magic = f32x2{12582912.f, 12582912.f};
                 const uint8_t* lp = reinterpret_cast<const uint8_t*>(patch[wave][buf]);
                 const uint32_t shp = bc(my_sh, k) >> 4;
-                const bool three = shp <= 11u; // 48-byte row pitch (see dma_patch)
-                const uint32_t ctr_off = three ? (uint32_t)(kPatchR * 48 + kPatchR) + shp - 49u * 0x4B400000u
-                                               : (uint32_t)(kPatchR * 64 + kPatchR) + shp - 65u * 0x4B400000u;
+                // 48-byte row pitch; the row starts at the aligned chunk (shp <= 11) or 12 bytes past it (see dma_patch)
+                const uint32_t ctr_off = (uint32_t)(kPatchR * 48 + kPatchR) + (shp <= 11u ? shp : shp - 12u) - 49u * 0x4B400000u;
                 unsigned long long bits[4];
 #pragma unroll
                 for(int t = 0; t < 4; ++t)
@@ -416,19 +403,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                     const f32x2 rr = (patX[t] * sa2 + patY[t] * ca2) + magic;
                     const f32x2 cc = (patX[t] * ca2 - patY[t] * sa2) + magic;
                     const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y);
-                    uint32_t i0, i1;
-                    if(three)
-                    {
-                        i0 = (r0 << 5) + (r0 << 4) + __float_as_uint(cc.x) + ctr_off; // row * 48 + byte in row
-                        i1 = (r1 << 5) + (r1 << 4) + __float_as_uint(cc.y) + ctr_off;
-                    }
-                    else
-                    {
-                        i0 = (r0 << 6) + __float_as_uint(cc.x) + ctr_off; // row * 64 + byte in row
-                        i1 = (r1 << 6) + __float_as_uint(cc.y) + ctr_off;
-                        i0 ^= (i0 >> 3) & 0x30u; // chunk swizzle
-                        i1 ^= (i1 >> 3) & 0x30u;
-                    }
+                    const uint32_t i0 = (r0 << 5) + (r0 << 4) + __float_as_uint(cc.x) + ctr_off; // row * 48 + byte in row
+                    const uint32_t i1 = (r1 << 5) + (r1 << 4) + __float_as_uint(cc.y) + ctr_off;
                     const int v0 = lp[i0];
                     const int v1 = lp[i1];
                     bits[t] = __ballot(v0 < v1);
@@ -442,7 +418,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                     reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k * kStr) * 32)[lane] = w;
                 }
             };
-            static_assert(kPatchBufs == 4, "phase A's vmcnt immediates are written for three windows in flight");
+            static_assert(kPatchBufs >= 2 && kPatchBufs <= 4, "phase A's vmcnt immediates are written for up to three windows in flight");
             static_assert(kDepth >= 1 && kDepth <= 5, "the vmcnt immediates below cover up to 5 patches in flight");
             for(int k = 0; k < n_here; ++k)
             {
