@@ -113,22 +113,22 @@ __device__ __forceinline__ void wave_sum_dpp2(int a, int b, int& ra, int& rb)
 }
 
 // Every WAVE is an independent worker (no workgroup barriers): it takes kBatch keypoints at a time through
-//  0. one LANE per keypoint: which level, which candidate word (kept in that lane's registers and
-//     broadcast later with v_readlane);
-//  A. moments, the whole wave on one keypoint: the radius-15 disc is 31 rows x 8 dwords; lane t (+64k)
-//     owns dword (row t/8, column group t%8), loads it with one unaligned dword load and folds it into
-//     m10/m01 with two signed v_dot4 against per-lane weight bytes (u resp. v inside the disc, 0
-//     outside; host-built table).  Pixels are biased by -128 (xor 0x80) to fit i8; the bias cancels
-//     exactly because the disc is symmetric (sum of u = sum of v = 0).  Integer sums: order-free.
-//     The loads of the next two keypoints are issued before the current two are reduced.
-//  B. one LANE per keypoint: fastAtan2, the f64 degree->radian product, util::cos/sin and the scalar
-//     outputs (coordinates, octave, angle, response) — the wave-uniform float work of phase C is
-//     thereby done once per keypoint instead of once per lane.
-//  C. descriptors, the whole wave on one keypoint: the 39x39 blurred patch is staged in LDS with
-//     coalesced aligned dword loads, the 512 rotated sample points are LDS byte gathers, and four
-//     ballots are the 32 descriptor bytes.  The global loads of the next two patches are in flight
-//     (in registers) while the current two are sampled.
-// Everything a wave needs about "its" keypoint is wave-uniform and kept in SGPRs (readlane).
+//  0. one LANE per keypoint: which level, which candidate word, the byte offsets of its two windows (kept in that
+//     lane's registers and broadcast later with v_readlane);
+//  A. moments, the whole wave on one keypoint: the radius-15 disc of the unblurred level comes in by LDS-DMA (31 rows
+//     x 48 bytes, two global_load_lds_dwordx4 per keypoint, three windows in flight in a per-wave LDS ring); lane t
+//     (+64k) reads dword (row t/8, column group t%8) and folds it into m10 / m01 with two signed v_dot4 against
+//     per-lane weight bytes (u resp. v inside the disc, 0 outside; host-built table).  Pixels are biased by -128
+//     (xor 0x80) to fit i8; the bias cancels exactly because the disc is symmetric (sum of u = sum of v = 0).
+//     Integer sums: order-free.
+//  B. one LANE per keypoint: fastAtan2, the f64 degree->radian product, util::cos/sin (or mslam_sincos_f32 in the
+//     cv::ORB mode) and the scalar outputs (coordinates, octave, angle, response) — the wave-uniform float work of
+//     phase C is thereby done once per keypoint instead of once per lane.
+//  C. descriptors, the whole wave on one keypoint: the 37 x 37 blurred patch comes in by LDS-DMA as well (37 rows x
+//     48 bytes, two instructions, same ring), the 512 rotated sample points are LDS byte gathers (both points of a
+//     pair rotated with packed-f32 arithmetic), and four ballots are the 32 descriptor bytes.
+// Everything a wave needs about "its" keypoint is wave-uniform and kept in SGPRs (readlane).  What bounds the kernel
+// is the L2 -> LDS window traffic, not arithmetic: DESIGN.md §4.6.
 constexpr int kBatch = 16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -374,12 +374,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
 
         // ---- C. descriptors
         {
-            // The 39 x 39 blurred patch comes in as 39 rows x 64 bytes from a 16-byte aligned start, by LDS-DMA
-            // (global_load_lds_dwordx4: per-lane source address, lane-linear destination, no VGPRs): lane t of
-            // instruction q fetches 16-byte chunk (t + 64 q) & 3 of row (t + 64 q) >> 2, which lands at byte
-            // 16 (t + 64 q) of the patch — exactly row-major with a 64-byte pitch.  Three DMA instructions per
-            // keypoint instead of seven register loads + seven LDS stores, and the patches of the next two
-            // keypoints are in flight while one is sampled.
+            // (the patches were requested by dma_patch above: 37 rows x 48 bytes each, lane-linear in LDS)
             auto describe = [&](int k, int buf) {
                 const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ca), k));
                 const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sa), k));
