@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (not part of the pytest suites: minutes of GPU + oracle time).
+
+    python tools/fuzz_parity.py [--seconds 120] [--seed 1]
+
+Draws frame sizes, pyramid shapes, thresholds and stop areas at random, for both detector modes, on synthetic
+texture / noise / low-contrast frames, and compares every output array of mslam_hip_detect with the oracle bit for
+bit.  Prints one line per mismatch with the parameters that reproduce it and exits non-zero if there was any."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import synth, __graft_entry__ as g
+pkg = g.load_package()
+import mslam_oracle as orc
+
+KEYS = ("xy", "desc", "octave", "angle", "response")
+
+
+def frame(rng, W, H, kind):
+    if kind == 0:
+        return synth.make_stream(1, W, H, seed=int(rng.integers(1 << 30)))[0]
+    if kind == 1:
+        return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    f = synth.make_stream(1, W, H, seed=int(rng.integers(1 << 30)))[0].astype(np.int32)
+    return np.clip(128 + (f - 128) // 4 + rng.integers(-3, 4, f.shape), 0, 255).astype(np.uint8)  # low contrast
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t0, n_ok, n_bad, n_skip = time.time(), 0, 0, 0
+    while time.time() - t0 < a.seconds:
+        cv = bool(rng.integers(2))
+        W, H = int(rng.integers(96, 900)), int(rng.integers(96, 700))
+        scale = float(np.float32(rng.choice([1.1, 1.2, 1.2, 1.25, 1.5, 2.0])))
+        levels = int(rng.integers(1, 9))
+        while min(W, H) / scale ** (levels - 1) < 80:
+            levels -= 1
+        kind = int(rng.integers(3))
+        thr = int(rng.integers(5, 40))
+        f = frame(rng, W, H, kind)
+        desc = dict(cv=cv, W=W, H=H, scale=scale, levels=levels, kind=kind, thr=thr)
+        try:
+            if cv:
+                n = int(rng.choice([0, 50, 500, 1000, 3000]))
+                edge = int(rng.integers(19, 40))
+                desc.update(n=n, edge=edge)
+                c = pkg.Context(width=W, height=H, detector=pkg.DETECTOR_CV_ORB, n_features=n, n_levels=levels,
+                                scale_factor=scale, ini_fast_thr=thr, edge_threshold=edge, max_keypoints=65535,
+                                max_candidates=262144)
+                ref = orc.cvorb_detect(f, orc.cvorb_params(n_features=n, n_levels=levels, scale_factor=scale,
+                                                           fast_threshold=thr, edge_threshold=edge))
+            else:
+                min_thr = int(rng.integers(2, thr + 1))
+                area = int(rng.choice([40, 150, 400, 1000, 4000]))
+                desc.update(min_thr=min_thr, area=area)
+                c = pkg.Context(width=W, height=H, n_levels=levels, scale_factor=scale, ini_fast_thr=thr,
+                                min_fast_thr=min_thr, min_node_area=area, max_keypoints=65535, max_candidates=262144)
+                ref = orc.detect(f, orc.params(n_levels=levels, scale_factor=scale, ini_fast_thr=thr, min_fast_thr=min_thr,
+                                               min_size=area))
+        except (pkg.MslamHipError, RuntimeError) as e:
+            n_skip += 1
+            print("skip", desc, str(e)[:80])
+            continue
+        try:
+            got = c.detect(f, max_out=65535)
+            bad = [k for k in KEYS if len(got[k]) != len(ref[k]) or not np.array_equal(got[k], ref[k])]
+            if len(ref["xy"]) > 65535:
+                bad = []
+        except pkg.MslamHipError as e:
+            bad = [] if e.code == pkg.E_CAPACITY else ["error: %s" % e]
+            if not bad:
+                n_skip += 1
+        c.close()
+        if bad:
+            n_bad += 1
+            print("MISMATCH", desc, bad, len(ref["xy"]), flush=True)
+        else:
+            n_ok += 1
+    print("fuzz: %d ok, %d mismatches, %d skipped in %.0f s" % (n_ok, n_bad, n_skip, time.time() - t0))
+    sys.exit(1 if n_bad else 0)
+
+
+if __name__ == "__main__":
+    main()
