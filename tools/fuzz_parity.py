@@ -28,12 +28,49 @@ def frame(rng, W, H, kind):
     return np.clip(128 + (f - 128) // 4 + rng.integers(-3, 4, f.shape), 0, 255).astype(np.uint8)  # low contrast
 
 
+def fuzz_matcher(rng, seconds):
+    """random descriptor sets (dense / tie-heavy: few distinct bits), both matcher kernels, ratio test on"""
+    c = pkg.Context(width=0, height=0, max_keypoints=6000)
+    t0, n_ok, n_bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        n_from, n_to = int(rng.integers(0, 5000)), int(rng.integers(0, 5000))
+        mode = int(rng.integers(3))
+        if mode == 0:
+            f = rng.integers(0, 256, (n_from, 32), dtype=np.uint8)
+            t = rng.integers(0, 256, (n_to, 32), dtype=np.uint8)
+        else:  # tie-heavy: descriptors drawn from a small pool with a few flipped bits
+            pool = rng.integers(0, 256, (max(2, int(rng.integers(2, 40))), 32), dtype=np.uint8)
+
+            def draw(n):
+                d = pool[rng.integers(0, len(pool), n)].copy()
+                if mode == 2 and n:
+                    d[np.arange(n), rng.integers(0, 32, n)] ^= (1 << rng.integers(0, 8, n)).astype(np.uint8)
+                return d
+            f, t = draw(n_from), draw(n_to)
+        ratio = float(rng.choice([0.5, 0.7, 0.9, 1.0]))
+        rf, rt = orc.match(f, t, ratio)
+        for kind in (pkg.MATCHER_AUTO, pkg.MATCHER_POPCOUNT):
+            c.set_matcher(kind)
+            gf, gt = c.match(f, t, ratio)
+            if not (np.array_equal(gf, rf) and np.array_equal(gt, rt)):
+                n_bad += 1
+                print("MISMATCH matcher", dict(n_from=n_from, n_to=n_to, mode=mode, ratio=ratio, kind=kind), flush=True)
+            else:
+                n_ok += 1
+    c.close()
+    print("fuzz matcher: %d ok, %d mismatches in %.0f s" % (n_ok, n_bad, time.time() - t0))
+    return n_bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--matcher", action="store_true", help="fuzz the matcher instead of the detectors")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
+    if a.matcher:
+        sys.exit(1 if fuzz_matcher(rng, a.seconds) else 0)
     t0, n_ok, n_bad, n_skip = time.time(), 0, 0, 0
     while time.time() - t0 < a.seconds:
         cv = bool(rng.integers(2))
