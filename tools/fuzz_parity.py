@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--matcher", action="store_true", help="fuzz the matcher instead of the detectors")
+    ap.add_argument("--max-width", type=int, default=900)
+    ap.add_argument("--max-height", type=int, default=700)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     if a.matcher:
@@ -74,7 +76,7 @@ def main():
     t0, n_ok, n_bad, n_skip = time.time(), 0, 0, 0
     while time.time() - t0 < a.seconds:
         cv = bool(rng.integers(2))
-        W, H = int(rng.integers(96, 900)), int(rng.integers(96, 700))
+        W, H = int(rng.integers(96, a.max_width)), int(rng.integers(96, a.max_height))
         scale = float(np.float32(rng.choice([1.1, 1.2, 1.2, 1.25, 1.5, 2.0])))
         levels = int(rng.integers(1, 9))
         while min(W, H) / scale ** (levels - 1) < 80:
