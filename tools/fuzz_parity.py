@@ -62,17 +62,76 @@ def fuzz_matcher(rng, seconds):
     return n_bad
 
 
+def fuzz_batch(rng, seconds):
+    """the batched device path (what bench.py times): random batch sizes and frame orders at random (small) frame sizes,
+    several batches chained per context; every frame's keypoints / descriptors / matches vs the oracle"""
+    import torch
+    t0, n_ok, n_bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        W, H = int(rng.integers(120, 400)), int(rng.integers(120, 300))
+        cv = bool(rng.integers(2))
+        B = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 64]))
+        uniq = synth.make_stream(5, W, H, seed=int(rng.integers(1 << 30)))
+        K = 4096
+        kw = dict(detector=pkg.DETECTOR_CV_ORB, n_features=300) if cv else dict(min_node_area=300)
+        c = pkg.Context(width=W, height=H, max_batch=B, max_keypoints=K, n_levels=4, **kw)
+        refs = [orc.cvorb_detect(f, orc.cvorb_params(n_features=300, n_levels=4)) if cv else
+                orc.detect(f, orc.params(n_levels=4, min_size=300)) for f in uniq]
+        prev = None
+        bad = []
+        for rep in range(3):
+            n = int(rng.integers(1, B + 1))
+            idx = rng.integers(0, 5, n)
+            frames = torch.from_numpy(np.ascontiguousarray(uniq[idx])).cuda()
+            c.detect_batch_dev(frames.data_ptr(), n)
+            c.match_batch_dev(0.7, True)
+            c.sync()
+            v = c.batch_view()
+            cnt = pkg.read_device(c, v.count, (n,), np.int32)
+            desc = pkg.read_device(c, v.desc, (n, K, 32), np.uint8)
+            xy = pkg.read_device(c, v.xy, (n, K, 2), np.float32)
+            ang = pkg.read_device(c, v.angle, (n, K), np.float32)
+            mc = pkg.read_device(c, v.match_count, (n,), np.int32)
+            mf = pkg.read_device(c, v.match_from, (n, K), np.int32)
+            mt = pkg.read_device(c, v.match_to, (n, K), np.int32)
+            for i in range(n):
+                r = refs[idx[i]]
+                m = len(r["xy"])
+                if cnt[i] != m or not (np.array_equal(desc[i, :m], r["desc"]) and np.array_equal(xy[i, :m], r["xy"])
+                                       and np.array_equal(ang[i, :m], r["angle"])):
+                    bad.append(("detect", rep, i))
+                p = prev if i == 0 else refs[idx[i - 1]]
+                if p is not None:
+                    rf, rt = orc.match(r["desc"], p["desc"])
+                    if mc[i] != len(rf) or not (np.array_equal(mf[i, :mc[i]], rf) and np.array_equal(mt[i, :mc[i]], rt)):
+                        bad.append(("match", rep, i))
+                elif mc[i] != 0:
+                    bad.append(("match0", rep, i))
+            prev = refs[idx[n - 1]]
+        c.close()
+        if bad:
+            n_bad += 1
+            print("MISMATCH batch", dict(W=W, H=H, cv=cv, B=B), bad[:4], flush=True)
+        else:
+            n_ok += 1
+    print("fuzz batch: %d ok, %d mismatches in %.0f s" % (n_ok, n_bad, time.time() - t0))
+    return n_bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--matcher", action="store_true", help="fuzz the matcher instead of the detectors")
+    ap.add_argument("--batch", action="store_true", help="fuzz the batched device path (detect_batch_dev + match_batch_dev)")
     ap.add_argument("--max-width", type=int, default=900)
     ap.add_argument("--max-height", type=int, default=700)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     if a.matcher:
         sys.exit(1 if fuzz_matcher(rng, a.seconds) else 0)
+    if a.batch:
+        sys.exit(1 if fuzz_batch(rng, a.seconds) else 0)
     t0, n_ok, n_bad, n_skip = time.time(), 0, 0, 0
     while time.time() - t0 < a.seconds:
         cv = bool(rng.integers(2))
