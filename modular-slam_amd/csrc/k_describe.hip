@@ -77,7 +77,7 @@ __device__ __forceinline__ float util_sin(float v)
 constexpr int kPatchR = 18;               // the rotated pattern reaches |18| (its radius is 18.38; the reference keeps a 19-px border)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 12;              // 48-byte rows: 37 needed bytes from a 16-byte aligned start, or from 12 bytes past one
-constexpr int kPatchBufs = 4;            // LDS patch ring per wave: one being sampled, three in flight (3 / 4 / 5 slots of 1776 bytes: 0.505 / 0.493 / 0.486 ms per 500 frames; 28 KB per workgroup, 5 workgroups per CU)
+constexpr int kPatchBufs = 5;            // LDS patch ring per wave: one being sampled, four in flight (3 / 4 / 5 slots of 1776 bytes: 0.505 / 0.493 / 0.486 ms per 500 frames; 35.5 KB per workgroup = 4 workgroups per CU: with 5 (4 slots) the frames in flight per XCD outgrow its L2 and the memory-side reads rise from 1.9 to 2.2 MB per frame)
 constexpr int kBlocksPerFrame = 32;
 
 // 64-lane integer sum with DPP adds (VALU only, no LDS crossbar); the total lands in lane 63
@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 const int younger = min(kDepthA, n_here - 1 - k); // windows issued after window k: 2 DMAs each
                 if(k + kDepthA < n_here)
                     dma_disc(k + kDepthA, (k + kDepthA) % kPatchBufs);
-                if(younger >= 3)
+                if(younger >= 4)
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+                else if(younger == 3)
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
                 else if(younger == 2)
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                     reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k * kStr) * 32)[lane] = w;
                 }
             };
-            static_assert(kPatchBufs >= 2 && kPatchBufs <= 4, "phase A's vmcnt immediates are written for up to three windows in flight");
+            static_assert(kPatchBufs >= 2 && kPatchBufs <= 5, "the vmcnt immediates of phases A and C cover up to four younger windows");
             static_assert(kDepth >= 1 && kDepth <= 5, "the vmcnt immediates below cover up to 5 patches in flight");
             for(int k = 0; k < n_here; ++k)
             {
