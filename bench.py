@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md, matrix cores)
-STAGE_KERNEL = {"gray": "mslam::k_gray4", "resize": "void mslam::k_resize_col<false>", "fast": "mslam::k_fast_cells",
+STAGE_KERNEL = {"pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "mslam::k_gray4", "resize": "void mslam::k_resize_col<false>", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur", "describe": "mslam::k_describe",
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
                 "backproject": "mslam::k_backproject"}
@@ -128,6 +128,9 @@ def parse():
     ap.add_argument("--voc-levels", type=int, default=6, help="vocabulary depth L (k=10): 6 -> 1e6 words")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU run) or gloo (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pnp", action="store_true",
+                    help="also estimate the frame-to-frame pose of every frame in the step (batched RANSAC PnP on the "
+                         "matches + back-projected points: mslam_hip_pnp_batch_dev)")
     ap.add_argument("--extras-timeout", type=int, default=300,
                     help="with several ranks: seconds the legs after the timed region may take before rank 0 prints "
                          "the line without them")
@@ -166,6 +169,9 @@ def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
         "match_knn2": 2 * 32 * n_kp + 16 * n_kp,
         "ratio_compact": 12 * n_kp + 8 * n_kp,
         "backproject": 8 * n_kp + 2 * n_kp + 25 * n_kp,
+        # matches (2 x i32) + 3-D point (24) + validity + pixel (8) in, correspondences (20) out; then read per hypothesis
+        "pnp_gather": 0.3 * n_kp * (8 + 25 + 8 + 20),
+        "pnp_ransac": 0.3 * n_kp * 20 * 100,
         # bow_tree = n*(32 + L*k*32) + n*12 out; vectors are <= n x (u32, f64)
         "bow_descend": n_kp * (32 + voc_L * voc_k * 32) + 12 * n_kp,
         "bow_vector": 12 * n_kp + 12 * n_kp,
@@ -300,6 +306,8 @@ def main():
         ctx.detect_batch_dev(d_frames.data_ptr() + off * frame_bytes, B)
         ctx.match_batch_dev(0.7, True)
         ctx.backproject_batch_dev(d_depth.data_ptr() + off * depth_bytes)
+        if a.pnp:
+            ctx.pnp_batch_dev(seed=i)
         if bow:
             ctx.bow_batch_dev(True)
             if world > 1:
@@ -359,7 +367,7 @@ def main():
         timed = timed_all
         # per-stage launch durations measured inside the timed region (HIP events on the launching stream);
         # a step's entries end with its last stage; a very long run stops recording at 8192 entries: keep whole steps
-        last = "bow_score" if a.bow else "backproject"
+        last = "bow_score" if a.bow else "pnp_ransac" if a.pnp else "backproject"
         ends = [i for i, (name, _) in enumerate(timed) if name == last]
         steps_cov = max(len(ends), 1)
         timed = timed[:ends[-1] + 1] if ends else timed
@@ -435,8 +443,9 @@ def main():
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: synthetic %dx%d RGB-D stream, %d-level ORB (reference defaults 1.2/20/7, min-area %d), "
-                                   "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame + depth back-projection%s" % (
+                                   "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame + depth back-projection%s%s" % (
                            cfg, a.width, a.height, a.levels, a.min_area,
+                           " + RANSAC PnP (100 hypotheses, 5 px) of every frame against its predecessor" if a.pnp else "",
                            (" + DBoW3 k=10 L=%d loop scoring vs last 64 frames%s" % (
                                a.voc_levels, " + all-gather of BoW vectors, cross-stream scores" if world > 1 else ""))
                            if a.bow else ""),

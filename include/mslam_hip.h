@@ -282,6 +282,27 @@ int mslam_hip_pnp_ransac(mslam_hip_ctx* ctx, const float* object_points, const f
                          double reprojection_error, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers,
                          int* n_inliers);
 
+/* Batched device form (the frame-to-frame tracking step of the RGB-D front end on device data): for every frame t >= 1 of
+ * the last batch, the matches (frame t -> frame t-1) of mslam_hip_match_batch_dev whose train keypoint has a valid
+ * back-projected point (mslam_hip_backproject_batch_dev) become the 3-D / 2-D correspondences
+ *   object = xyz[t-1][to] (cast to float, rgbd_feature_frontend.cpp:232-254 / cv_ransac_pnp.cpp:22-31), image = xy[t][from],
+ * in match order, and one RANSAC PnP per frame (one workgroup each, no extrinsic guess, seed + t as the sampling seed)
+ * estimates the pose of camera t in the coordinates of camera t-1.  Frame 0 has no predecessor inside the batch
+ * (status 0).  Results: mslam_hip_pnp_view. */
+int mslam_hip_pnp_batch_dev(mslam_hip_ctx* ctx, double fx, double fy, double cx, double cy, int iterations,
+                            double reprojection_error, uint64_t seed);
+typedef struct
+{
+    int32_t capacity;          /* per-frame stride of the correspondence arrays (max_keypoints)                 */
+    const double* pose;        /* [max_batch][16]: R row-major (9), t (3), inliers, best hypothesis, status, cost;
+                                * status 1 = a model was found, 0 = none (fewer than 4 points / 4 inliers)      */
+    const int32_t* n_points;   /* [max_batch] correspondences of the frame                                      */
+    const float* object_points; /* [max_batch][capacity][3]                                                     */
+    const float* image_points;  /* [max_batch][capacity][2]                                                     */
+    const uint8_t* inliers;     /* [max_batch][capacity] consensus mask of the best hypothesis                  */
+} mslam_hip_pnp_view;
+int mslam_hip_get_pnp_view(mslam_hip_ctx* ctx, mslam_hip_pnp_view* view);
+
 /* ---- test / debug access to intermediate stages (host copies; synchronises) -----------------------*/
 enum
 {

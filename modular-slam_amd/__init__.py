@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
     "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size", "mslam_hip_qlz_decompress",
-    "mslam_hip_pnp_ransac",
+    "mslam_hip_pnp_ransac", "mslam_hip_pnp_batch_dev", "mslam_hip_get_pnp_view",
 ]
 
 
@@ -68,6 +68,11 @@ class BatchView(C.Structure):
 
 class PointsView(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("xyz", C.c_void_p), ("valid", C.c_void_p)]
+
+
+class PnpView(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("pose", C.c_void_p), ("n_points", C.c_void_p), ("object_points", C.c_void_p),
+                ("image_points", C.c_void_p), ("inliers", C.c_void_p)]
 
 
 class BowView(C.Structure):
@@ -230,6 +235,18 @@ class Context:
     def points_view(self):
         v = PointsView()
         self._chk(self.L.mslam_hip_get_points_view(self._h, C.byref(v)))
+        return v
+
+    def pnp_batch_dev(self, focal=(525.0, 525.0), principal=(319.5, 239.5), iterations=100, reprojection_error=5.0, seed=0):
+        """one RANSAC PnP per frame of the last batch from its matches + the previous frame's back-projected points
+        (after detect_batch_dev, match_batch_dev, backproject_batch_dev); results: pnp_view()"""
+        self._chk(self.L.mslam_hip_pnp_batch_dev(self._h, C.c_double(focal[0]), C.c_double(focal[1]), C.c_double(principal[0]),
+                                                 C.c_double(principal[1]), int(iterations), C.c_double(reprojection_error),
+                                                 C.c_uint64(seed)))
+
+    def pnp_view(self):
+        v = PnpView()
+        self._chk(self.L.mslam_hip_get_pnp_view(self._h, C.byref(v)))
         return v
 
     # ---- PnP RANSAC (cv_ransac_pnp.cpp:14-85) ---------------------------------------------------

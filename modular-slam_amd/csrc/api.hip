@@ -381,7 +381,8 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
                     c->d_blur,    c->d_cv_ofs, c->d_cv_coef, c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_to, c->d_hm_out,
-                    c->d_xyz, c->d_valid};
+                    c->d_xyz, c->d_valid, c->d_pnp_obj, c->d_pnp_img, c->d_pnp_n, c->d_pnp_counts, c->d_pnp_hyp, c->d_pnp_out,
+                    c->d_pnp_mask};
     for(void* b : bufs)
         if(b)
             (void)hipFree(b);

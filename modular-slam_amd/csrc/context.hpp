@@ -112,6 +112,12 @@ struct mslam_hip_ctx
     // RGB-D back-projection outputs (allocated on first use)
     double* d_xyz = nullptr;
     uint8_t* d_valid = nullptr;
+    // batched PnP (allocated on first use)
+    float *d_pnp_obj = nullptr, *d_pnp_img = nullptr;
+    int32_t *d_pnp_n = nullptr, *d_pnp_counts = nullptr;
+    double *d_pnp_hyp = nullptr, *d_pnp_out = nullptr;
+    uint8_t* d_pnp_mask = nullptr;
+    int pnp_iterations = 0;
 
     mslam::BowState* bow = nullptr;
 

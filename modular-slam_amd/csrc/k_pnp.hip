@@ -171,6 +171,20 @@ __device__ __forceinline__ bool project(const Cam& k, const double* R, const dou
     return true;
 }
 
+// inlier test of point P / pixel (pu, pv) under (R, t): reprojection error <= thr, written without the two divisions
+// (for X.z > 0:  (fx X.x / X.z + cx - pu)^2 + (fy X.y / X.z + cy - pv)^2 <= thr^2
+//            <=> (fx X.x + (cx - pu) X.z)^2 + (fy X.y + (cy - pv) X.z)^2 <= thr^2 X.z^2);
+// the scoring loop evaluates it 100 x n times per problem and an f64 division is ~25 instructions.  The CPU checker of
+// the tests evaluates the same form.
+__device__ __forceinline__ bool is_inlier(const Cam& k, const double* R, const double* t, V3 P, double pu, double pv, double thr2)
+{
+    const V3 X = mulR(R, P) + v3(t[0], t[1], t[2]);
+    if(!(X.z > 1e-9))
+        return false;
+    const double eu = k.fx * X.x + (k.cx - pu) * X.z, ev = k.fy * X.y + (k.cy - pv) * X.z;
+    return eu * eu + ev * ev <= thr2 * (X.z * X.z);
+}
+
 // P3P on points 0..2 of the sample (Grunert's quartic), the 4th point picks among the solutions
 __device__ bool p3p_hypothesis(const Cam& k, const V3* P, const double* uv, double* R, double* t)
 {
@@ -241,24 +255,46 @@ __device__ bool p3p_hypothesis(const Cam& k, const V3* P, const double* uv, doub
 
 constexpr int kPnpThreads = 256;
 
-// fixed-order workgroup sum of `cnt` doubles per thread (acc[cnt]); the totals land in red[0..cnt)
-__device__ void wg_sum(double* acc, int cnt, double* red /*[cnt][kPnpThreads]*/, int tid)
+// fixed-order workgroup sum of `cnt` doubles per thread (acc[cnt]); the totals land in red[0..cnt).  Butterfly inside
+// each wave (cross-lane moves, no memory), then the four wave totals are added in wave order: one barrier pair instead
+// of a nine-barrier LDS tree, and 1.2 KB of LDS instead of 57 KB (which held the batched kernel to 2 workgroups per CU).
+constexpr int kPnpRed = 32 + 28 * (kPnpThreads / 64); // doubles of LDS: totals [32] + per-wave partials [28][waves]
+constexpr int kPnpLdsPts = 2048;                      // points staged in LDS for the scoring loop (40 KB)
+constexpr int kPnpLdsHyp = 256;                       // hypotheses (12 doubles + a count) kept in LDS up to this many
+template <int CNT>
+__device__ __forceinline__ void wg_sum(double* acc, double* red, int tid)
 {
-    for(int j = 0; j < cnt; ++j)
-        red[j * kPnpThreads + tid] = acc[j];
-    __syncthreads();
-    for(int o = kPnpThreads / 2; o > 0; o >>= 1)
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int W = kPnpThreads / 64;
+    // CNT independent butterflies, fully unrolled: the cross-lane moves of different sums overlap
+#pragma unroll
+    for(int o = 32; o > 0; o >>= 1)
     {
-        if(tid < o)
-            for(int j = 0; j < cnt; ++j)
-                red[j * kPnpThreads + tid] += red[j * kPnpThreads + tid + o];
-        __syncthreads();
+#pragma unroll
+        for(int j = 0; j < CNT; ++j)
+            acc[j] += __shfl_xor(acc[j], o);
     }
+    if(lane == 0)
+    {
+#pragma unroll
+        for(int j = 0; j < CNT; ++j)
+            red[32 + j * W + wave] = acc[j];
+    }
+    __syncthreads();
+    if(tid < CNT)
+    {
+        double t = red[32 + tid * W];
+#pragma unroll
+        for(int w = 1; w < W; ++w)
+            t += red[32 + tid * W + w];
+        red[tid] = t;
+    }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
+// one problem, one workgroup (shared by the single-problem kernel and the batched one)
+__device__ __forceinline__ void pnp_problem(const PnpArgs& a, double* red /* LDS [kPnpRed] doubles + [kPnpLdsPts][5] floats */)
 {
-    extern __shared__ double red[]; // [28][kPnpThreads]
     __shared__ int s_best, s_cnt;
     __shared__ double sR[9], st[3], sNew[12];
     __shared__ double s_lambda, s_cost;
@@ -266,6 +302,14 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
     const int tid = threadIdx.x;
     const Cam cam{a.fx, a.fy, a.cx, a.cy};
     const int n = a.n;
+    // hypotheses and their inlier counts: LDS when they fit (every wave re-reads them; a global round trip per hypothesis
+    // was a third of the scoring time), else the caller's global arrays
+    double* l_hyp = red + kPnpRed;
+    int32_t* l_cnt = reinterpret_cast<int32_t*>(l_hyp + kPnpLdsHyp * 12);
+    float* pts = reinterpret_cast<float*>(l_cnt + kPnpLdsHyp);
+    uint8_t* l_mask = reinterpret_cast<uint8_t*>(pts + 5 * kPnpLdsPts);
+    double* hyp = a.iterations <= kPnpLdsHyp ? l_hyp : a.hyp;
+    int32_t* counts = a.iterations <= kPnpLdsHyp ? l_cnt : a.counts;
 
     // ---- 1. hypotheses: thread h draws 4 distinct points and solves P3P
     for(int h = tid; h < a.iterations; h += kPnpThreads)
@@ -304,38 +348,59 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
             }
             ok = p3p_hypothesis(cam, P, uv, R, t);
         }
-        double* hp = a.hyp + (size_t)h * 12;
+        double* hp = hyp + (size_t)h * 12;
         for(int j = 0; j < 9; ++j)
             hp[j] = ok ? R[j] : 0.0;
         for(int j = 0; j < 3; ++j)
             hp[9 + j] = ok ? t[j] : 0.0;
-        a.counts[h] = ok ? 0 : -1;
+        counts[h] = ok ? 0 : -1;
     }
     __syncthreads();
 
     // ---- 2. score every hypothesis against every point: wave w takes hypotheses w, w+4, ...
+    // (the first kPnpLdsPts points as 5 floats each in LDS: every wave reads every point once per hypothesis)
+    const int n_lds = min(n, kPnpLdsPts);
+    for(int i = tid; i < n_lds; i += kPnpThreads)
+    {
+        pts[5 * i] = a.obj[3 * i], pts[5 * i + 1] = a.obj[3 * i + 1], pts[5 * i + 2] = a.obj[3 * i + 2];
+        pts[5 * i + 3] = a.img[2 * i], pts[5 * i + 4] = a.img[2 * i + 1];
+    }
+    __syncthreads();
     {
         const int lane = tid & 63, wave = tid >> 6;
         for(int h = wave; h < a.iterations; h += kPnpThreads / 64)
         {
-            if(a.counts[h] < 0)
+            if(counts[h] < 0)
                 continue;
-            const double* hp = a.hyp + (size_t)h * 12;
+            // the hypothesis in registers (wave-uniform), the points from LDS when they fit
+            double hp[12];
+            for(int j = 0; j < 12; ++j)
+                hp[j] = hyp[(size_t)h * 12 + j];
             int c = 0;
-            for(int i = lane; i < n; i += 64)
+            // four points per lane and step: with one wave per SIMD (the P3P code takes 174 VGPRs) only independent work
+            // inside the wave hides the f64 and LDS latencies.  Two loops so that the LDS one is pure ds_read code.
+            if(n <= n_lds)
             {
-                double u, v;
-                const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
-                if(project(cam, hp, hp + 9, P, u, v))
-                {
-                    const double du = u - (double)a.img[2 * i], dv = v - (double)a.img[2 * i + 1];
-                    c += (du * du + dv * dv <= a.thr2) ? 1 : 0;
-                }
+                auto one = [&](int i) -> int {
+                    if(i >= n)
+                        return 0;
+                    const float* po = pts + 5 * i;
+                    return is_inlier(cam, hp, hp + 9, v3((double)po[0], (double)po[1], (double)po[2]), (double)po[3],
+                                     (double)po[4], a.thr2) ? 1 : 0;
+                };
+                for(int i = lane; i < n; i += 256)
+                    c += one(i) + one(i + 64) + one(i + 128) + one(i + 192);
+            }
+            else
+            {
+                for(int i = lane; i < n; i += 64)
+                    c += is_inlier(cam, hp, hp + 9, v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]),
+                                   (double)a.img[2 * i], (double)a.img[2 * i + 1], a.thr2) ? 1 : 0;
             }
             for(int o = 32; o > 0; o >>= 1)
                 c += __shfl_xor(c, o);
             if(lane == 0)
-                a.counts[h] = c;
+                counts[h] = c;
         }
     }
     __syncthreads();
@@ -343,8 +408,8 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
     {
         int best = -1, bc = -1;
         for(int h = 0; h < a.iterations; ++h)
-            if(a.counts[h] > bc)
-                bc = a.counts[h], best = h;
+            if(counts[h] > bc)
+                bc = counts[h], best = h;
         s_best = best;
         s_cnt = bc;
     }
@@ -364,18 +429,14 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
     }
     // ---- 3. consensus set of the best hypothesis
     {
-        const double* hp = a.hyp + (size_t)best * 12;
+        const double* hp = hyp + (size_t)best * 12;
         for(int i = tid; i < n; i += kPnpThreads)
         {
-            double u, v;
             const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
-            bool in = false;
-            if(project(cam, hp, hp + 9, P, u, v))
-            {
-                const double du = u - (double)a.img[2 * i], dv = v - (double)a.img[2 * i + 1];
-                in = du * du + dv * dv <= a.thr2;
-            }
+            const bool in = is_inlier(cam, hp, hp + 9, P, (double)a.img[2 * i], (double)a.img[2 * i + 1], a.thr2);
             a.mask[i] = in ? 1 : 0;
+            if(i < n_lds)
+                l_mask[i] = in ? 1 : 0;
         }
         if(tid < 9)
             sR[tid] = a.use_guess ? a.R0[tid] : hp[tid];
@@ -387,22 +448,41 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
     __syncthreads();
 
     // ---- 4. damped Gauss-Newton on the consensus set: X = exp(w) R P + t + dt
+    // point i of the consensus set (false: not in it); from LDS when the problem fits (workgroup-uniform choice)
+    const bool in_lds = n <= n_lds;
+    auto fetch = [&](int i, V3& P, double& pu, double& pv) -> bool {
+        if(in_lds)
+        {
+            if(!l_mask[i])
+                return false;
+            const float* po = pts + 5 * i;
+            P = v3((double)po[0], (double)po[1], (double)po[2]);
+            pu = (double)po[3], pv = (double)po[4];
+            return true;
+        }
+        if(!a.mask[i])
+            return false;
+        P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
+        pu = (double)a.img[2 * i], pv = (double)a.img[2 * i + 1];
+        return true;
+    };
     auto cost_of = [&](const double* R, const double* t) -> double {
         double c = 0.0;
         for(int i = tid; i < n; i += kPnpThreads)
-            if(a.mask[i])
+        {
+            V3 P;
+            double pu, pv, u, v;
+            if(!fetch(i, P, pu, pv))
+                continue;
+            if(project(cam, R, t, P, u, v))
             {
-                double u, v;
-                const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
-                if(project(cam, R, t, P, u, v))
-                {
-                    const double du = u - (double)a.img[2 * i], dv = v - (double)a.img[2 * i + 1];
-                    c += du * du + dv * dv;
-                }
-                else
-                    c += 1e12; // behind the camera
+                const double du = u - pu, dv = v - pv;
+                c += du * du + dv * dv;
             }
-        wg_sum(&c, 1, red, tid);
+            else
+                c += 1e12; // behind the camera
+        }
+        wg_sum<1>(&c, red, tid);
         const double total = red[0];
         __syncthreads();
         return total;
@@ -414,16 +494,18 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
         for(int j = 0; j < 27; ++j)
             acc[j] = 0.0;
         for(int i = tid; i < n; i += kPnpThreads)
-            if(a.mask[i])
             {
-                const V3 P = v3((double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2]);
+                V3 P;
+                double pu, pv;
+                if(!fetch(i, P, pu, pv))
+                    continue;
                 const V3 Y = mulR(sR, P); // rotated, not translated
                 const V3 X = Y + v3(st[0], st[1], st[2]);
                 if(!(X.z > 1e-9))
                     continue;
                 const double iz = 1.0 / X.z;
-                const double ru = cam.fx * X.x * iz + cam.cx - (double)a.img[2 * i];
-                const double rv = cam.fy * X.y * iz + cam.cy - (double)a.img[2 * i + 1];
+                const double ru = cam.fx * X.x * iz + cam.cx - pu;
+                const double rv = cam.fy * X.y * iz + cam.cy - pv;
                 // d(u, v)/dX, dX/dw = -[Y]x, dX/dt = I
                 const double ux = cam.fx * iz, uz = -cam.fx * X.x * iz * iz, vy = cam.fy * iz, vz = -cam.fy * X.y * iz * iz;
                 const double Ju[6] = {uz * Y.y, ux * Y.z - uz * Y.x, -ux * Y.y, ux, 0.0, uz};
@@ -435,56 +517,76 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
                 for(int r = 0; r < 6; ++r)
                     acc[21 + r] += Ju[r] * ru + Jv[r] * rv;
             }
-        wg_sum(acc, 27, red, tid);
+        wg_sum<27>(acc, red, tid);
         if(tid == 0)
         {
-            double H[36], g[6];
-            int k = 0;
+            // 6 x 6 damped normal equations, solved in registers (every loop below has constant bounds and is unrolled; with
+            // early exits the arrays lived in scratch memory and this single-thread section took most of an iteration)
+            double H[6][6], g[6];
+            {
+                int k = 0;
+#pragma unroll
+                for(int r = 0; r < 6; ++r)
+#pragma unroll
+                    for(int c2 = r; c2 < 6; ++c2)
+                    {
+                        H[r][c2] = red[k];
+                        H[c2][r] = red[k];
+                        ++k;
+                    }
+            }
+#pragma unroll
             for(int r = 0; r < 6; ++r)
-                for(int c2 = r; c2 < 6; ++c2)
-                    H[r * 6 + c2] = H[c2 * 6 + r] = red[(k++) * kPnpThreads];
+                g[r] = red[21 + r];
+#pragma unroll
             for(int r = 0; r < 6; ++r)
-                g[r] = red[(21 + r) * kPnpThreads];
-            for(int r = 0; r < 6; ++r)
-                H[r * 6 + r] += s_lambda * H[r * 6 + r] + 1e-12;
+                H[r][r] += s_lambda * H[r][r] + 1e-12;
             // Cholesky H = L L^T, solve H d = -g
-            double L[36];
+            double L[6][6];
             bool ok = true;
-            for(int r = 0; r < 6 && ok; ++r)
+#pragma unroll
+            for(int r = 0; r < 6; ++r)
+#pragma unroll
                 for(int c2 = 0; c2 <= r; ++c2)
                 {
-                    double sum = H[r * 6 + c2];
+                    double sum = H[r][c2];
+#pragma unroll
                     for(int j = 0; j < c2; ++j)
-                        sum -= L[r * 6 + j] * L[c2 * 6 + j];
+                        sum -= L[r][j] * L[c2][j];
                     if(r == c2)
                     {
-                        if(!(sum > 0.0))
-                        {
-                            ok = false;
-                            break;
-                        }
-                        L[r * 6 + r] = sqrt(sum);
+                        ok = ok && sum > 0.0;
+                        L[r][r] = sqrt(ok ? sum : 1.0);
                     }
                     else
-                        L[r * 6 + c2] = sum / L[c2 * 6 + c2];
+                        L[r][c2] = sum / L[c2][c2];
                 }
             double d[6] = {0, 0, 0, 0, 0, 0};
-            if(ok)
             {
                 double y[6];
+#pragma unroll
                 for(int r = 0; r < 6; ++r)
                 {
                     double sum = -g[r];
+#pragma unroll
                     for(int j = 0; j < r; ++j)
-                        sum -= L[r * 6 + j] * y[j];
-                    y[r] = sum / L[r * 6 + r];
+                        sum -= L[r][j] * y[j];
+                    y[r] = sum / L[r][r];
                 }
+#pragma unroll
                 for(int r = 5; r >= 0; --r)
                 {
                     double sum = y[r];
+#pragma unroll
                     for(int j = r + 1; j < 6; ++j)
-                        sum -= L[j * 6 + r] * d[j];
-                    d[r] = sum / L[r * 6 + r];
+                        sum -= L[j][r] * d[j];
+                    d[r] = sum / L[r][r];
+                }
+                if(!ok)
+                {
+#pragma unroll
+                    for(int r = 0; r < 6; ++r)
+                        d[r] = 0.0;
                 }
             }
             // R' = exp(w) R (Rodrigues), t' = t + dt
@@ -525,7 +627,9 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
             else
             {
                 s_lambda *= 10.0;
-                s_stop = s_lambda > 1e12 ? 1 : 0;
+                // a rejected step shorter than 1e-9 means the optimum is reached to rounding: without this test the loop
+                // spends its remaining iterations raising lambda to 1e12
+                s_stop = (s_lambda > 1e12 || step < 1e-9) ? 1 : 0;
             }
         }
         if(trial < cost)
@@ -544,6 +648,87 @@ __global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
         a.out[14] = 1.0;
         a.out[15] = cost;
     }
+}
+
+__global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac(PnpArgs a)
+{
+    extern __shared__ double red[]; // [kPnpRed]
+    pnp_problem(a, red);
+}
+
+// ---- batched form: correspondences of every frame from the device-resident match / back-projection results ---------
+struct PnpBatchArgs
+{
+    PnpArgs proto;        // camera, iterations, threshold, seed; pointers = frame 0's slices
+    const int32_t* n;     // [B] correspondences per frame
+    int cap;              // per-frame stride (keypoints)
+};
+
+// frame t: matches (from = keypoint of t, to = keypoint of t-1) with a valid 3-D point at `to`, in match order
+__global__ __launch_bounds__(256) void k_pnp_gather(const int32_t* __restrict__ mfrom, const int32_t* __restrict__ mto,
+                                                    const int32_t* __restrict__ mcount, const float* __restrict__ xy,
+                                                    const double* __restrict__ xyz, const uint8_t* __restrict__ valid, int cap,
+                                                    float* __restrict__ obj, float* __restrict__ img, int32_t* __restrict__ n_out)
+{
+    __shared__ uint32_t wsum[4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = t >= 1 ? min(mcount[t], cap) : 0;
+    const size_t ft = (size_t)t * cap, fp = (size_t)(t - 1) * cap;
+    uint32_t running = 0;
+    for(int base = 0; base < m; base += 256)
+    {
+        const int i = base + tid;
+        int from = 0, to = 0;
+        bool ok = false;
+        if(i < m)
+        {
+            from = mfrom[ft + i], to = mto[ft + i];
+            ok = (unsigned)from < (unsigned)cap && (unsigned)to < (unsigned)cap && valid[fp + to] != 0;
+        }
+        const unsigned long long b = __ballot(ok);
+        if(lane == 0)
+            wsum[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for(int k = 0; k < 4; ++k)
+        {
+            pre += k < wave ? wsum[k] : 0;
+            tot += wsum[k];
+        }
+        if(ok)
+        {
+            const size_t o = ft + running + pre + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            const double* P = xyz + (fp + to) * 3;
+            obj[o * 3] = (float)P[0], obj[o * 3 + 1] = (float)P[1], obj[o * 3 + 2] = (float)P[2];
+            img[o * 2] = xy[(ft + from) * 2], img[o * 2 + 1] = xy[(ft + from) * 2 + 1];
+        }
+        running += tot;
+        __syncthreads();
+    }
+    if(tid == 0)
+        n_out[t] = (int32_t)running;
+}
+
+__global__ __launch_bounds__(kPnpThreads) void k_pnp_ransac_batch(PnpBatchArgs b)
+{
+    extern __shared__ double red[]; // [kPnpRed]
+    const int t = blockIdx.x;
+    PnpArgs a = b.proto;
+    a.n = b.n[t];
+    a.obj += (size_t)t * b.cap * 3;
+    a.img += (size_t)t * b.cap * 2;
+    a.mask += (size_t)t * b.cap;
+    a.hyp += (size_t)t * a.iterations * 12;
+    a.counts += (size_t)t * a.iterations;
+    a.out += (size_t)t * 16;
+    a.seed += (unsigned long long)t;
+    if(a.n < 4)
+    {
+        if(threadIdx.x < 16)
+            a.out[threadIdx.x] = threadIdx.x == 13 ? -1.0 : 0.0; // status 0: no model
+        return;
+    }
+    pnp_problem(a, red);
 }
 
 } // namespace mslam
@@ -642,7 +827,7 @@ extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points
     a.thr2 = reprojection_error * reprojection_error;
     a.seed = seed;
     a.hyp = d_hyp, a.counts = d_counts, a.mask = d_mask, a.out = d_out;
-    const size_t lds = (size_t)28 * kPnpThreads * 8;
+    const size_t lds = (size_t)kPnpRed * 8 + (size_t)kPnpLdsHyp * (96 + 4) + (size_t)kPnpLdsPts * 21;
     PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if(e == hipSuccess)
         hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(kPnpThreads), lds, c->stream, a);
@@ -667,5 +852,105 @@ extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points
         std::memcpy(inliers, mask.data(), (size_t)n);
     if(n_inliers)
         *n_inliers = (int)out[12];
+    return MSLAM_HIP_OK;
+}
+
+
+static int pnp_batch_buffers(mslam_hip_ctx* c, int iterations)
+{
+    const size_t B = (size_t)c->p.max_batch, K = (size_t)c->p.max_keypoints;
+    if(c->d_pnp_obj && c->pnp_iterations >= iterations)
+        return MSLAM_HIP_OK;
+    void* old[] = {c->d_pnp_obj, c->d_pnp_img, c->d_pnp_n, c->d_pnp_counts, c->d_pnp_hyp, c->d_pnp_out, c->d_pnp_mask};
+    for(void* p : old)
+        if(p)
+            (void)hipFree(p);
+    c->d_pnp_obj = c->d_pnp_img = nullptr, c->d_pnp_n = c->d_pnp_counts = nullptr, c->d_pnp_hyp = c->d_pnp_out = nullptr;
+    c->d_pnp_mask = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->d_pnp_obj), B * K * 12);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_pnp_img), B * K * 8);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_pnp_n), B * 4);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_pnp_counts), B * (size_t)iterations * 4);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_pnp_hyp), B * (size_t)iterations * 12 * 8);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_pnp_out), B * 16 * 8);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_pnp_mask), B * K);
+    if(e == hipSuccess) e = hipMemset(c->d_pnp_n, 0, B * 4);
+    if(e == hipSuccess) e = hipMemset(c->d_pnp_out, 0, B * 16 * 8);
+    if(e != hipSuccess)
+    {
+        c->err = std::string("pnp_batch_dev: ") + hipGetErrorString(e);
+        return MSLAM_HIP_E_RUNTIME;
+    }
+    c->pnp_iterations = iterations;
+    return MSLAM_HIP_OK;
+}
+
+extern "C" int mslam_hip_pnp_batch_dev(mslam_hip_ctx* c, double fx, double fy, double cx, double cy, int iterations,
+                                       double reprojection_error, uint64_t seed)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    auto fail = [&](int code, const char* msg) {
+        c->err = msg;
+        return code;
+    };
+    if(iterations < 1 || iterations > 4096 || !(reprojection_error > 0) || !(fx != 0.0) || !(fy != 0.0))
+        return fail(MSLAM_HIP_E_INVALID, "pnp_batch_dev: bad argument (1..4096 iterations)");
+    if(c->n_last < 1 || !c->d_xyz)
+        return fail(MSLAM_HIP_E_INVALID, "pnp_batch_dev: needs a detect batch, its matches and its back-projection");
+    if(hipSetDevice(c->p.device) != hipSuccess)
+        return fail(MSLAM_HIP_E_RUNTIME, "pnp_batch_dev: hipSetDevice");
+    int rc = pnp_batch_buffers(c, iterations);
+    if(rc)
+        return rc;
+    rc = mslam_hip_join_matcher(c); // the matches come from the matcher's stream
+    if(rc)
+        return rc;
+    const int K = c->p.max_keypoints, n = c->n_last;
+    {
+        StageScope t(c, "pnp_gather");
+        hipLaunchKernelGGL(k_pnp_gather, dim3(n), dim3(256), 0, c->stream, c->d_mfrom, c->d_mto, c->d_mcount,
+                           c->d_xy + (size_t)K * 2, c->d_xyz, c->d_valid, K, c->d_pnp_obj, c->d_pnp_img, c->d_pnp_n);
+    }
+    PnpBatchArgs b{};
+    PnpArgs& a = b.proto;
+    a.obj = c->d_pnp_obj, a.img = c->d_pnp_img, a.n = 0;
+    a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy;
+    a.use_guess = 0;
+    a.iterations = iterations;
+    a.thr2 = reprojection_error * reprojection_error;
+    a.seed = seed;
+    a.hyp = c->d_pnp_hyp, a.counts = c->d_pnp_counts, a.mask = c->d_pnp_mask, a.out = c->d_pnp_out;
+    b.n = c->d_pnp_n;
+    b.cap = K;
+    const size_t lds = (size_t)kPnpRed * 8 + (size_t)kPnpLdsHyp * (96 + 4) + (size_t)kPnpLdsPts * 21;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac_batch),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if(attr != hipSuccess)
+        return fail(MSLAM_HIP_E_RUNTIME, "pnp_batch_dev: hipFuncSetAttribute");
+    {
+        StageScope t(c, "pnp_ransac");
+        hipLaunchKernelGGL(k_pnp_ransac_batch, dim3(n), dim3(kPnpThreads), lds, c->stream, b);
+    }
+    if(hipGetLastError() != hipSuccess)
+        return fail(MSLAM_HIP_E_RUNTIME, "pnp_batch_dev: launch failed");
+    return MSLAM_HIP_OK;
+}
+
+extern "C" int mslam_hip_get_pnp_view(mslam_hip_ctx* c, mslam_hip_pnp_view* v)
+{
+    if(!c || !v)
+        return MSLAM_HIP_E_INVALID;
+    if(!c->d_pnp_obj)
+    {
+        c->err = "get_pnp_view: mslam_hip_pnp_batch_dev has not run";
+        return MSLAM_HIP_E_INVALID;
+    }
+    v->capacity = c->p.max_keypoints;
+    v->pose = c->d_pnp_out;
+    v->n_points = c->d_pnp_n;
+    v->object_points = c->d_pnp_obj;
+    v->image_points = c->d_pnp_img;
+    v->inliers = c->d_pnp_mask;
     return MSLAM_HIP_OK;
 }

@@ -109,8 +109,13 @@ def hypothesis(obj, img, cam, idx):
 
 
 def inliers_of(R, t, obj, img, cam, thr):
-    pr, ok = project(R, t, obj.astype(np.float64), cam)
-    return ok & (np.sum((pr - img.astype(np.float64)) ** 2, 1) <= thr * thr)
+    """reprojection error <= thr, in the division-free form the kernel evaluates (k_pnp.hip: is_inlier):
+    (fx X + (cx - u) Z)^2 + (fy Y + (cy - v) Z)^2 <= thr^2 Z^2 for Z > 1e-9"""
+    X = obj.astype(np.float64) @ R.T + t
+    uv = img.astype(np.float64)
+    eu = cam[0] * X[:, 0] + (cam[2] - uv[:, 0]) * X[:, 2]
+    ev = cam[1] * X[:, 1] + (cam[3] - uv[:, 1]) * X[:, 2]
+    return (X[:, 2] > 1e-9) & (eu * eu + ev * ev <= (thr * thr) * (X[:, 2] * X[:, 2]))
 
 
 def refine(R, t, obj, img, cam, mask, iters=50):
@@ -143,7 +148,7 @@ def refine(R, t, obj, img, cam, mask, iters=50):
                 break
         else:
             lam *= 10
-            if lam > 1e12:
+            if lam > 1e12 or np.linalg.norm(d) < 1e-9:   # rejected step below rounding level: converged
                 break
     return R, t, c
 

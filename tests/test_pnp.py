@@ -85,3 +85,63 @@ def test_gpu_pnp_matches_ground_truth_and_oracle(pkg):
     with pytest.raises(pkg.MslamHipError):
         c.pnp_ransac(obj[:3], img[:3], CAM[:2], CAM[2:])
     c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_pnp_batch_on_device_results(pkg):
+    """the batched device form: correspondences of every frame gathered on the device from the matches and the previous
+    frame's back-projected points; one PnP per frame.  A fronto-parallel plane at 2 m seen by a camera that moves
+    parallel to it: frame t is frame t-1 shifted by whole pixels, so the pose between consecutive frames is
+    R = I, t = (dx Z / fx, dy Z / fy, 0).  Checked: the gathered correspondences against a host-side gather, every
+    pose against the single-problem entry point on the same data and seed, the oracle on two frames, ground truth."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    B, K, Z = 6, 4096, 2.0
+    base = synth.make_stream(1, 640 + 64, 480 + 48, seed=11)[0]
+    shifts = [(3 * t, 2 * t) for t in range(B)]                      # (dx, dy): the window moves right/down = camera moves
+    frames = np.stack([np.ascontiguousarray(base[dy:dy + 480, dx:dx + 640]) for dx, dy in shifts])
+    depth = np.full((B, 480, 640), int(Z * 5000), np.uint16)
+    c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K)
+    c.detect_batch_dev(torch.from_numpy(frames).cuda().data_ptr(), B)
+    c.match_batch_dev(0.7, False)
+    d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
+    c.backproject_batch_dev(d_depth.data_ptr(), focal=CAM[:2], principal=CAM[2:])
+    c.pnp_batch_dev(CAM[:2], CAM[2:], seed=40)
+    c.sync()
+    v, pv, nv = c.batch_view(), c.points_view(), c.pnp_view()
+    xy = pkg.read_device(c, v.xy, (B, K, 2), np.float32)
+    mc = pkg.read_device(c, v.match_count, (B,), np.int32)
+    mf = pkg.read_device(c, v.match_from, (B, K), np.int32)
+    mt = pkg.read_device(c, v.match_to, (B, K), np.int32)
+    xyz = pkg.read_device(c, pv.xyz, (B, K, 3), np.float64)
+    ok = pkg.read_device(c, pv.valid, (B, K), np.uint8)
+    pose = pkg.read_device(c, nv.pose, (B, 16), np.float64)
+    npts = pkg.read_device(c, nv.n_points, (B,), np.int32)
+    obj = pkg.read_device(c, nv.object_points, (B, K, 3), np.float32)
+    img = pkg.read_device(c, nv.image_points, (B, K, 2), np.float32)
+    inl = pkg.read_device(c, nv.inliers, (B, K), np.uint8)
+    assert npts[0] == 0 and pose[0, 14] == 0.0                       # no predecessor inside the batch
+    single = pkg.Context(width=0, height=0)
+    for t in range(1, B):
+        keep = ok[t - 1, mt[t, :mc[t]]] != 0
+        ref_obj = xyz[t - 1, mt[t, :mc[t]][keep]].astype(np.float32)
+        ref_img = xy[t, mf[t, :mc[t]][keep]]
+        n = int(npts[t])
+        assert n == len(ref_obj) and n > 300
+        assert np.array_equal(obj[t, :n], ref_obj) and np.array_equal(img[t, :n], ref_img)
+        assert pose[t, 14] == 1.0
+        R, tv = pose[t, :9].reshape(3, 3), pose[t, 9:12]
+        r1, t1, m1 = single.pnp_ransac(ref_obj, ref_img, CAM[:2], CAM[2:], seed=40 + t)
+        assert np.array_equal(m1, inl[t, :n]) and int(pose[t, 12]) == int(m1.sum())
+        assert rot_err(po.rodrigues(r1), R) < 1e-9 and np.array_equal(t1, tv)
+        dx, dy = shifts[t][0] - shifts[t - 1][0], shifts[t][1] - shifts[t - 1][1]
+        # a point at pixel x in frame t-1 is at x - dx in frame t: X_t = X_{t-1} - (dx Z / fx, dy Z / fy, 0)
+        assert rot_err(R, np.eye(3)) < 0.2 and np.linalg.norm(tv - [-dx * Z / CAM[0], -dy * Z / CAM[1], 0]) < 0.01
+        assert m1.sum() > 0.9 * n
+        if t <= 2:
+            ref = po.pnp_ransac(ref_obj, ref_img, CAM, seed=40 + t)
+            # (rot_err goes through arccos near 1: ~1e-6 degrees is its own resolution there)
+            assert np.array_equal(ref["mask"], m1) and np.abs(R - ref["R"]).max() < 1e-9 and np.linalg.norm(tv - ref["t"]) < 1e-7
+    single.close()
+    c.close()
