@@ -382,7 +382,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_to, c->d_hm_out,
                     c->d_xyz, c->d_valid, c->d_pnp_obj, c->d_pnp_img, c->d_pnp_n, c->d_pnp_counts, c->d_pnp_hyp, c->d_pnp_out,
-                    c->d_pnp_mask};
+                    c->d_pnp_mask, c->d_blur_waves};
     for(void* b : bufs)
         if(b)
             (void)hipFree(b);
@@ -660,6 +660,13 @@ static int create_impl(mslam_hip_ctx* c)
     // + 64: the patch loads of k_describe may run a few bytes past the last row of the last frame
     HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 256));
     HIPCHK(c, dmalloc(c->d_blur, B * g.slab + 256));
+    {
+        std::vector<BlurWave> bw;
+        build_blur_waves(g, bw);
+        c->blur_wpf = (int)bw.size();
+        HIPCHK(c, dmalloc(c->d_blur_waves, bw.size()));
+        HIPCHK(c, hipMemcpy(c->d_blur_waves, bw.data(), bw.size() * sizeof(BlurWave), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, dmalloc(c->d_cell_cnt, B * g.n_cells));
     HIPCHK(c, dmalloc(c->d_cell_kp, B * g.n_cells * (size_t)kCellCap));
     QuadArgs& q = c->quad;
@@ -902,7 +909,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             HIPCHK(c, hipStreamWaitEvent(c->blur_stream[k], c->ev_blur_fork[k], 0));
             {
                 StageScope t(c, "blur", c->blur_stream[k]);
-                launch_blur(c->d_pyr, c->d_blur, g, f0, nf, c->blur_stream[k]);
+                launch_blur(c->d_pyr, c->d_blur, g, c->d_blur_waves, c->blur_wpf, f0, nf, c->blur_stream[k]);
             }
             HIPCHK(c, hipEventRecord(c->ev_blur_join[k], c->blur_stream[k]));
         }
@@ -915,13 +922,13 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
         else
         {
             StageScope t(c, "blur", cs);
-            launch_blur(c->d_pyr, c->d_blur, g, f0, nf, cs);
+            launch_blur(c->d_pyr, c->d_blur, g, c->d_blur_waves, c->blur_wpf, f0, nf, cs);
         }
         } // in-tree detector
         if(cv_mode)
         {
             StageScope t(c, "blur", cs);
-            launch_blur(c->d_pyr, c->d_blur, g, f0, nf, cs);
+            launch_blur(c->d_pyr, c->d_blur, g, c->d_blur_waves, c->blur_wpf, f0, nf, cs);
         }
         {
             StageScope t(c, "describe", cs);

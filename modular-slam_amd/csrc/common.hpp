@@ -112,7 +112,16 @@ struct QuadArgs
     unsigned min_size;
 };
 void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_frames, hipStream_t s);
-void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, int frame0, int n_frames, hipStream_t s);
+// k_blur2: one descriptor per wave of a frame (level-uniform waves)
+struct BlurWave
+{
+    int level, strip0, band0; // first 4-px strip and first 32-row band of the wave
+    int16_t lg_spg;           // log2(strips per band row inside the wave): 6 / 5 / 4 / 3 -> 1 / 2 / 4 / 8 bands per wave
+    int16_t generic;          // 1: the level is lower than 38 rows, every row takes the per-lane reflect path
+    float inv_bsx;            // lg_spg == 0: lanes are consecutive (band, strip) items starting at item strip0; 1 / strips per row
+};
+void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, const BlurWave* d_waves, int wpf, int frame0, int n_frames,
+                 hipStream_t s);
 struct DescArgs
 {
     const uint8_t* pyr;

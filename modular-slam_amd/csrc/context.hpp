@@ -11,6 +11,7 @@ namespace mslam
 struct BowState; // k_bow.hip
 void bow_destroy(BowState*);
 void set_blur_taps(const int* taps);
+void build_blur_waves(const Geometry& g, std::vector<BlurWave>& out);
 
 struct StageTimer
 {
@@ -80,6 +81,8 @@ struct mslam_hip_ctx
     uint8_t* d_stage = nullptr; // one frame of BGR for the host-pointer entry point
     uint8_t* d_pyr = nullptr;
     uint8_t* d_blur = nullptr;
+    mslam::BlurWave* d_blur_waves = nullptr; // k_blur2 wave descriptors of one frame
+    int blur_wpf = 0;
     uint32_t* d_cell_cnt = nullptr;
     uint32_t* d_cell_kp = nullptr;
     mslam::QuadArgs quad{};
