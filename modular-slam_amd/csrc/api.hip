@@ -661,11 +661,29 @@ static int create_impl(mslam_hip_ctx* c)
     HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 256));
     HIPCHK(c, dmalloc(c->d_blur, B * g.slab + 256));
     {
+        // k_level.hip (fused gray + blur): needs dword columns, 32-bit batch offsets and the exact float index split
+        {
+            const char* e = getenv("MSLAM_HIP_FUSED_LEVELS");
+            const int want = e ? atoi(e) : kMaxLevels;
+            const char* k = getenv("MSLAM_HIP_LEVEL_K6");
+            c->level_k6 = k ? std::max(1, atoi(k)) : 5;
+            const bool fits = (p.width & 3) == 0 && (double)B * p.width * p.height * 3 < 4294967296.0 &&
+                              (double)B * g.slab < 4294967296.0 && (size_t)B * (p.width / 4) < (1u << 22) && p.height >= 8;
+            int n_fused = fits ? 1 : 0;
+            // levels l > 0 (resize + blur): the level must be on the 12-byte-window tables of k_resize_col
+            while(n_fused >= 1 && n_fused < p.n_levels && c->rs_q[n_fused] != SIZE_MAX && g.lv[n_fused].h >= 8 &&
+                  (size_t)B * ((g.lv[n_fused].w + 3) / 4) < (1u << 22))
+                ++n_fused;
+            c->fused_levels = std::max(0, std::min(want, n_fused));
+        }
         std::vector<BlurWave> bw;
-        build_blur_waves(g, bw);
+        build_blur_waves(g, c->fused_levels, bw);
         c->blur_wpf = (int)bw.size();
-        HIPCHK(c, dmalloc(c->d_blur_waves, bw.size()));
-        HIPCHK(c, hipMemcpy(c->d_blur_waves, bw.data(), bw.size() * sizeof(BlurWave), hipMemcpyHostToDevice));
+        if(!bw.empty())
+        {
+            HIPCHK(c, dmalloc(c->d_blur_waves, bw.size()));
+            HIPCHK(c, hipMemcpy(c->d_blur_waves, bw.data(), bw.size() * sizeof(BlurWave), hipMemcpyHostToDevice));
+        }
     }
     HIPCHK(c, dmalloc(c->d_cell_cnt, B * g.n_cells));
     HIPCHK(c, dmalloc(c->d_cell_kp, B * g.n_cells * (size_t)kCellCap));
@@ -773,6 +791,32 @@ int mslam_hip_sync(mslam_hip_ctx* c)
     return check_flags(c);
 }
 
+// one level l > 0 produced and blurred in one pass (k_level.hip)
+static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, const uint32_t* ycoef, int exact, int f0, int nf,
+                                hipStream_t cs)
+{
+    const Geometry& g = c->geom;
+    const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
+    ResizeBlurArgs ra{};
+    ra.pyr = c->d_pyr;
+    ra.blur = c->d_blur;
+    ra.slab = g.slab;
+    ra.src_off = sl.offset, ra.sh = sl.h, ra.spitch = sl.pitch;
+    ra.dst_off = dl.offset, ra.dw = dl.w, ra.dh = dl.h, ra.dpitch = dl.pitch;
+    ra.qt = c->d_rs_qt + 3 * c->rs_q[l];
+    ra.yofs = yofs;
+    ra.ycoef = ycoef;
+    ra.frame0 = f0, ra.n_frames = nf;
+    ra.quads = (dl.w + 3) / 4;
+    ra.inv_quads = 1.0f / (float)ra.quads;
+    ra.k6 = std::max(1, std::min(std::min(c->level_k6, 9), (dl.h - 2) / 6));
+    ra.need_mask = c->rs_need[l];
+    ra.exact = exact;
+    ra.dump_off = g.slab - 256;
+    ra.bk = make_blur_k();
+    launch_resize_blur(ra, cs);
+}
+
 // the kernel sequence of one detect batch into the current output set (no set switching, no events)
 static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
 {
@@ -795,7 +839,24 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             HIPCHK(c, hipStreamWaitEvent(cs, c->ev_fork, 0));
         {
             StageScope t(c, "gray", cs);
-            launch_gray(d_bgr, c->d_pyr, g, f0, nf, cs);
+            if(c->fused_levels >= 1)
+            {
+                GrayBlurArgs ga{};
+                ga.bgr = d_bgr;
+                ga.pyr = c->d_pyr;  // (level 0 starts the slab)
+                ga.blur = c->d_blur;
+                ga.dump_off = g.slab - 256;
+                ga.W = g.W, ga.H = g.H, ga.pitch = g.lv[0].pitch;
+                ga.slab = g.slab;
+                ga.n_frames = nf, ga.frame0 = f0;
+                ga.quads = g.W / 4;
+                ga.inv_quads = 1.0f / (float)ga.quads;
+                ga.k6 = std::max(1, std::min(c->level_k6, (g.H - 2) / 6));
+                ga.bk = make_blur_k();
+                launch_gray_blur(ga, cs);
+            }
+            else
+                launch_gray(d_bgr, c->d_pyr, g, f0, nf, cs);
         }
         const bool cv_mode = c->p.detector == MSLAM_HIP_DETECTOR_CV_ORB;
         if(cv_mode)
@@ -806,6 +867,11 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 for(int l = 1; l < g.n_levels; ++l)
                 {
                     const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
+                    if(l < c->fused_levels)
+                    {
+                        enqueue_resize_blur(c, l, c->d_cv_ofs + c->cv_y[l], c->d_cv_coef + c->cv_y[l], 1, f0, nf, cs);
+                        continue;
+                    }
                     if(c->rs_q[l] != SIZE_MAX)
                     {
                         ResizeColArgs ca{};
@@ -867,6 +933,11 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             StageScope t(c, "resize", cs);
             for(int l = 1; l < g.n_levels; ++l)
             {
+                if(l < c->fused_levels)
+                {
+                    enqueue_resize_blur(c, l, c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], 0, f0, nf, cs);
+                    continue;
+                }
                 if(c->rs_q[l] != SIZE_MAX)
                 {
                     const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
@@ -901,7 +972,8 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             launch_fast(c->d_pyr, g, c->d_cells, c->d_cell_cnt, c->d_cell_kp, c->p.ini_fast_thr, c->p.min_fast_thr, f0,
                         nf, cs);
         }
-        const bool forked = c->fork_blur && !c->profiling;
+        const bool blur_needed = c->fused_levels < g.n_levels;
+        const bool forked = c->fork_blur && !c->profiling && blur_needed;
         if(forked)
         {
             // quadtree (latency-bound, LDS-heavy) and blur (vector-ALU-bound, no LDS) only read the pyramid: side by side
@@ -919,13 +991,13 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
         }
         if(forked)
             HIPCHK(c, hipStreamWaitEvent(cs, c->ev_blur_join[k], 0));
-        else
+        else if(blur_needed)
         {
             StageScope t(c, "blur", cs);
             launch_blur(c->d_pyr, c->d_blur, g, c->d_blur_waves, c->blur_wpf, f0, nf, cs);
         }
         } // in-tree detector
-        if(cv_mode)
+        if(cv_mode && c->fused_levels < g.n_levels)
         {
             StageScope t(c, "blur", cs);
             launch_blur(c->d_pyr, c->d_blur, g, c->d_blur_waves, c->blur_wpf, f0, nf, cs);

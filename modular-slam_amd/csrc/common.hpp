@@ -112,13 +112,56 @@ struct QuadArgs
     unsigned min_size;
 };
 void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_frames, hipStream_t s);
-// k_blur2: one descriptor per wave of a frame (level-uniform waves)
+// the 7 Gaussian taps arranged for the kernels (k_blur2, k_level.hip)
+struct BlurK
+{
+    uint32_t ta[3], tb[4], tc[4]; // horizontal taps positioned for output pixel j on window dwords A / B / C (tc[0] unused)
+    uint32_t t01, t23, t45, t6;   // vertical taps as u16 pairs
+};
+BlurK make_blur_k();
+// k_level.hip: level 0 = gray + blur in one pass
+struct GrayBlurArgs
+{
+    const uint8_t* bgr; // batch of BGR frames
+    uint8_t* pyr;       // raw slab of frame 0 (level 0 starts it)
+    uint8_t* blur;      // blurred slab of frame 0
+    int W, H, pitch;
+    unsigned slab;
+    int n_frames, frame0;
+    int quads;          // W / 4
+    float inv_quads;
+    int k6;             // rows per block = 6 k6 + 2
+    unsigned dump_off;  // offset (from the slab's first byte) of the 256 pad bytes that end every frame's slab
+    BlurK bk;
+};
+void launch_gray_blur(const GrayBlurArgs& a, hipStream_t s);
+// k_level.hip: level l > 0 = resize (k_resize_col's tables) + blur in one pass
+struct ResizeBlurArgs
+{
+    uint8_t* pyr;
+    uint8_t* blur;
+    unsigned slab;
+    int src_off, sh, spitch, dst_off, dw, dh, dpitch;
+    const uint4* qt;       // [quads][3], as ResizeColArgs
+    const int32_t* yofs;   // [dh]
+    const uint32_t* ycoef; // [dh] b0 | b1 << 16
+    int frame0, n_frames;
+    int quads;
+    float inv_quads;
+    int k6;        // rows per block = 6 k6 + 2 (<= 58: the block's row table lives in lane registers)
+    int need_mask; // bit k: pixel k of some quad takes its pair from dwords (1,2)
+    int exact;     // 0: INTER_LINEAR, 1: INTER_LINEAR_EXACT
+    unsigned dump_off; // offset of the 256 pad bytes that end every frame's slab
+    BlurK bk;
+};
+void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s);
+// k_blur2: one descriptor per wave of a frame (level-uniform waves of 64 consecutive (band, strip) items)
 struct BlurWave
 {
-    int level, strip0, band0; // first 4-px strip and first 32-row band of the wave
-    int16_t lg_spg;           // log2(strips per band row inside the wave): 6 / 5 / 4 / 3 -> 1 / 2 / 4 / 8 bands per wave
-    int16_t generic;          // 1: the level is lower than 38 rows, every row takes the per-lane reflect path
-    float inv_bsx;            // lg_spg == 0: lanes are consecutive (band, strip) items starting at item strip0; 1 / strips per row
+    int level;
+    int item0;       // first item: item = band * strips_per_row + strip (4-px strips, 32-row bands)
+    int generic;     // 1: the level is lower than 38 rows, every row takes the per-lane reflect path
+    float inv_bsx;   // 1 / strips per row
 };
 void launch_blur(const uint8_t* d_pyr, uint8_t* d_blur, const Geometry& g, const BlurWave* d_waves, int wpf, int frame0, int n_frames,
                  hipStream_t s);

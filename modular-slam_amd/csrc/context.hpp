@@ -11,7 +11,7 @@ namespace mslam
 struct BowState; // k_bow.hip
 void bow_destroy(BowState*);
 void set_blur_taps(const int* taps);
-void build_blur_waves(const Geometry& g, std::vector<BlurWave>& out);
+void build_blur_waves(const Geometry& g, int first_level, std::vector<BlurWave>& out);
 
 struct StageTimer
 {
@@ -83,6 +83,8 @@ struct mslam_hip_ctx
     uint8_t* d_blur = nullptr;
     mslam::BlurWave* d_blur_waves = nullptr; // k_blur2 wave descriptors of one frame
     int blur_wpf = 0;
+    int fused_levels = 0;  // levels 0 .. fused_levels-1 are produced and blurred by k_level.hip; k_blur2 takes the rest
+    int level_k6 = 10;     // k_level.hip: rows per block = 6 k6 + 2
     uint32_t* d_cell_cnt = nullptr;
     uint32_t* d_cell_kp = nullptr;
     mslam::QuadArgs quad{};

@@ -1,0 +1,472 @@
+// k_level.hip — one pyramid level per launch, produced AND blurred in the same pass (round 3).
+//
+//   level 0 : BGR -> gray (frame.cpp:6-27)                                        + 7x7 sigma-2 blur (DCF:797-798)
+//   level l : cv::resize(level l-1, INTER_LINEAR [_EXACT in the cv::ORB mode]) (DCF:839) + the same blur
+//
+// Why fused: the blur of a level was a kernel of its own that read the level plane back (1.17 MB of the 8.2 MB per frame
+// the pipeline moved in round 2) and was bound by that read, not by its arithmetic.  Here the freshly produced row never
+// leaves the registers before it is filtered: the raw plane is written once (FAST, the orientation and the next level
+// read it), the blurred plane is written once, nothing is read back.
+//
+// Shape (both kernels): lanes are flattened over (frame, 4-pixel column) of the level, as in k_resize_col, and walk DOWN
+// a block of R = 6k + 2 rows (+ 6 halo rows, REFLECT_101 at the top and bottom: the row index is wave-uniform, so the
+// reflection is scalar).  Per row a lane owns ONE dword of raw pixels; the 7-tap needs the dword left and right of it:
+// these come from the neighbouring LANES with two DPP wave shifts (no LDS, no re-load).  Lanes 0 and 63 of every wave
+// are halo lanes (they produce their dword but no output): waves overlap by one lane on each side, 62 of 64 lanes are
+// productive.  At the first / last column of a frame REFLECT_101 replaces the neighbour (v_perm selectors computed once
+// per lane, identity for interior lanes): a frame boundary inside a wave needs no special case.
+//   horizontal 7-tap: 10 v_dot4_u32_u8 on the three dwords against taps shifted to the pixel's position (k_blur.hip)
+//   vertical 7-tap  : v_dot2_u32_u16 on (row, row+1) pairs kept in a 6-deep register ring; the row loop is unrolled by
+//                     six so that the ring is addressed statically
+// The arithmetic is the one of k_gray4 / k_resize_col / k_blur2, whose stand-alone forms stay as the generic fallbacks
+// (widths that are not a multiple of 4 at level 0, scale factors beyond the 12-byte window, batches beyond 32-bit offsets).
+#include "common.hpp"
+#include <type_traits>
+
+namespace mslam
+{
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t lv_dot2u(uint32_t pair, uint32_t taps, uint32_t acc)
+{
+    u16x2_t a, b;
+    a.x = (unsigned short)(pair & 0xFFFF);
+    a.y = (unsigned short)(pair >> 16);
+    b.x = (unsigned short)(taps & 0xFFFF);
+    b.y = (unsigned short)(taps >> 16);
+    return __builtin_amdgcn_udot2(a, b, acc, false);
+}
+
+// per-lane REFLECT_101 selectors for the window [x0-4, x0+8) held as (L, B, R) = (left neighbour, own, right neighbour)
+struct EdgeSel
+{
+    uint32_t selA, selB, selT, selU, maskT;
+};
+__device__ __forceinline__ EdgeSel edge_selectors(int x0, int w)
+{
+    EdgeSel e{0, 0, 0, 0, 0};
+#pragma unroll
+    for(int i = 0; i < 12; ++i)
+    {
+        int col = x0 - 4 + i;
+        if(col < 0)
+            col = -col;
+        else if(col >= w)
+            col = 2 * (w - 1) - col;
+        int s = col - (x0 - 4); // source byte index inside the unreflected window
+        if(s < 0 || s > 11)
+            s = i; // only feeds outputs that are discarded
+        const int b = i & 3;
+        if(i < 4)
+            e.selA |= (uint32_t)(s <= 7 ? s : i) << (8 * b);
+        else if(i < 8)
+            e.selB |= (uint32_t)(s <= 7 ? s : i) << (8 * b);
+        else if(s < 4)
+        {
+            e.selT |= (uint32_t)s << (8 * b);
+            e.maskT |= 0xFFu << (8 * b);
+        }
+        else
+            e.selU |= (uint32_t)(s - 4) << (8 * b);
+    }
+    return e;
+}
+
+// the blur's register state of one lane: six (row, row+1) pair rows and the previous row's horizontal sums
+struct BlurRing
+{
+    uint32_t pr[6][4];
+    uint32_t hprev[4];
+};
+
+// Feeds raw row i (i % 6 == PH) of the lane's column into the filter.  Returns true and the blurred dword of row i - 3
+// (the block's output row i - 6) when EMIT.
+template <int PH, bool EMIT>
+__device__ __forceinline__ uint32_t blur_feed(BlurRing& st, uint32_t B, const EdgeSel& e, const BlurK& k)
+{
+    // neighbour dwords: lane l-1's and lane l+1's raw dword of this row (DPP wave shifts; lanes 0 / 63 are halo lanes)
+    const uint32_t L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B, 0x138, 0xF, 0xF, true); // wave_shr:1
+    const uint32_t R = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B, 0x130, 0xF, 0xF, true); // wave_shl:1
+    const uint32_t A2 = __builtin_amdgcn_perm(B, L, e.selA);
+    const uint32_t B2 = __builtin_amdgcn_perm(B, L, e.selB);
+    const uint32_t T = __builtin_amdgcn_perm(B, L, e.selT);
+    const uint32_t U = __builtin_amdgcn_perm(R, B, e.selU);
+    const uint32_t C2 = (T & e.maskT) | (U & ~e.maskT);
+    uint32_t hv[4];
+    hv[0] = __builtin_amdgcn_udot4(A2, k.ta[0], __builtin_amdgcn_udot4(B2, k.tb[0], 0u, false), false);
+    hv[1] = __builtin_amdgcn_udot4(A2, k.ta[1], __builtin_amdgcn_udot4(B2, k.tb[1], __builtin_amdgcn_udot4(C2, k.tc[1], 0u, false), false), false);
+    hv[2] = __builtin_amdgcn_udot4(A2, k.ta[2], __builtin_amdgcn_udot4(B2, k.tb[2], __builtin_amdgcn_udot4(C2, k.tc[2], 0u, false), false), false);
+    hv[3] = __builtin_amdgcn_udot4(B2, k.tb[3], __builtin_amdgcn_udot4(C2, k.tc[3], 0u, false), false);
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+        st.pr[(PH + 5) % 6][j] = st.hprev[j] | (hv[j] << 16); // pair (row i-1, row i)
+    uint32_t out = 0;
+    if(EMIT)
+    {
+        uint32_t acc[4];
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+        {
+            acc[j] = lv_dot2u(st.pr[PH][j], k.t01, 32768u);           // rows i-6, i-5
+            acc[j] = lv_dot2u(st.pr[(PH + 2) % 6][j], k.t23, acc[j]); // rows i-4, i-3
+            acc[j] = lv_dot2u(st.pr[(PH + 4) % 6][j], k.t45, acc[j]); // rows i-2, i-1
+            acc[j] += __umul24(hv[j], k.t6);                          // row i
+        }
+        out = __builtin_amdgcn_perm(acc[1], acc[0], 0x0C0C0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020C0Cu);
+    }
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+        st.hprev[j] = hv[j];
+    return out;
+}
+
+// REFLECT_101 of a wave-uniform row index (|y|, then min(y, 2 (h - 1) - y))
+__device__ __forceinline__ int reflect_row(int y, int h)
+{
+    const int ya = y < 0 ? -y : y;
+    const int yb = 2 * (h - 1) - ya;
+    return ya < yb ? ya : yb;
+}
+
+__device__ __forceinline__ uint32_t lv_gray_px(uint32_t c0, uint32_t c1, uint32_t c2)
+{
+    // (0.299f*c0 + 0.587f*c1) + 0.114f*c2 with every operation individually rounded (no contraction), frame.cpp:13-19
+    float v = __fadd_rn(__fmul_rn(0.299f, (float)c0), __fmul_rn(0.587f, (float)c1));
+    v = __fadd_rn(v, __fmul_rn(0.114f, (float)c2));
+    v = fminf(255.0f, v);
+    return (uint32_t)(int)v;
+}
+__device__ __forceinline__ uint32_t lv_gray4(uint32_t a, uint32_t b, uint32_t c)
+{
+    // bytes: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3   (little endian)
+    const uint32_t p0 = lv_gray_px(a & 0xFF, (a >> 8) & 0xFF, (a >> 16) & 0xFF);
+    const uint32_t p1 = lv_gray_px(a >> 24, b & 0xFF, (b >> 8) & 0xFF);
+    const uint32_t p2 = lv_gray_px((b >> 16) & 0xFF, b >> 24, c & 0xFF);
+    const uint32_t p3 = lv_gray_px((c >> 8) & 0xFF, (c >> 16) & 0xFF, c >> 24);
+    return p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+}
+
+struct Bgr3
+{
+    uint32_t a, b, c;
+};
+
+// ---- level 0: gray + blur --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int n_items = a.n_frames * a.quads;
+    const int item_raw = gw * 62 - 1 + lane;
+    if(gw * 62 >= n_items)
+        return; // whole wave beyond the last item (wave-uniform)
+    const bool productive = lane >= 1 && lane <= 62 && item_raw < n_items;
+    const int item = max(0, min(item_raw, n_items - 1));
+    const int f = (int)(((float)item + 0.5f) * a.inv_quads); // item / quads, exact for items < 2^22 (host check)
+    const int q = item - f * a.quads;
+    const int R = 6 * a.k6 + 2;
+    const int y0 = min((int)blockIdx.y * R, a.H - R); // the last block ends at the last row (host: R <= H)
+    const EdgeSel e = edge_selectors(4 * q, a.W);
+    const uint32_t src_v = (uint32_t)(f + a.frame0) * (uint32_t)(a.W * a.H * 3) + 12u * (uint32_t)q;
+    // Every lane stores every row, unconditionally: the compiler can then count the stores in its vmcnt waits and the
+    // loads stay two rows ahead (a store that may or may not issue makes every counted wait stricter).  Halo lanes and
+    // rows outside the block write to the dump words: the 256 pad bytes that end the frame's slab (api.hip: g.slab).
+    // The store offsets advance by one row per row in vector registers (two fast adds per row); halo lanes advance by 0.
+    const uint32_t dump_v = (uint32_t)(f + a.frame0) * a.slab + a.dump_off + 4u * (uint32_t)lane;
+    const uint32_t pitch_v = productive ? (uint32_t)a.pitch : 0u;
+    const uint32_t col_v = (uint32_t)(f + a.frame0) * a.slab + 4u * (uint32_t)q;
+    uint32_t raw_v = productive ? col_v + (uint32_t)(y0 - 3) * (uint32_t)a.pitch : dump_v;  // raw row of block row i = 0
+    uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.pitch : dump_v; // blurred row of block row i = 0 (used from i = 6 on)
+    const uint32_t row_bytes = (uint32_t)a.W * 3u;
+
+    auto load = [&](int i) {
+        const int y = reflect_row(y0 - 3 + i, a.H);
+        const uint8_t* rowp = a.bgr + (size_t)y * row_bytes; // wave-uniform
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + src_v);
+        return Bgr3{p[0], p[1], p[2]};
+    };
+    BlurRing st;
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+        st.hprev[j] = 0;
+    Bgr3 ring[3];
+    ring[0] = load(0);
+    ring[1] = load(1);
+
+    // one row: i = i0 + PH, PH = i % 6 (static); RAW: the row belongs to the block (rows 3 .. R+2), BLUR: i >= 6
+    auto row = [&](auto ph, auto emit, auto sraw, int i, bool raw) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr bool EMIT = decltype(emit)::value;
+        constexpr bool SRAW = decltype(sraw)::value; // false for block rows 0 .. 2: no raw store is emitted at all
+        ring[(PH + 2) % 3] = load(min(i + 2, R + 5));
+        const Bgr3 w = ring[PH % 3];
+        const uint32_t g = lv_gray4(w.a, w.b, w.c);
+        if(SRAW)
+            *reinterpret_cast<uint32_t*>(a.pyr + (raw ? raw_v : dump_v)) = g; // rows 3 .. R+2 need no reflection
+        const uint32_t o = blur_feed<PH, EMIT>(st, g, e, a.bk);
+        if(EMIT)
+            *reinterpret_cast<uint32_t*>(a.blur + blur_v) = o;
+        raw_v += pitch_v;
+        blur_v += pitch_v;
+    };
+    using std::integral_constant;
+#define MSLAM_ROW(PH, EMIT, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, ((PH) >= 3 || (EMIT))>{}, I, RAW)
+    // rows 0 .. 5: fill the ring (rows 3, 4, 5 are the block's first rows)
+    MSLAM_ROW(0, false, 0, false);
+    MSLAM_ROW(1, false, 1, false);
+    MSLAM_ROW(2, false, 2, false);
+    MSLAM_ROW(3, false, 3, true);
+    MSLAM_ROW(4, false, 4, true);
+    MSLAM_ROW(5, false, 5, true);
+#pragma unroll 1
+    for(int i0 = 6; i0 < R + 4; i0 += 6)
+    {
+        MSLAM_ROW(0, true, i0, true);
+        MSLAM_ROW(1, true, i0 + 1, true);
+        MSLAM_ROW(2, true, i0 + 2, true);
+        MSLAM_ROW(3, true, i0 + 3, true);
+        MSLAM_ROW(4, true, i0 + 4, true);
+        MSLAM_ROW(5, true, i0 + 5, i0 + 5 < R + 3);
+    }
+    // rows R+4, R+5 (R + 4 = 6 (k6 + 1)): halo rows below the block
+    MSLAM_ROW(0, true, R + 4, false);
+    MSLAM_ROW(1, true, R + 5, false);
+#undef MSLAM_ROW
+}
+
+// ---- level l > 0: resize + blur --------------------------------------------------------------------------------------
+// The interpolation is k_resize_col's (host tables: per destination quad a 12-byte source window, v_perm selectors and
+// weight pairs; per destination row the source row and the weight pair).  Rows are walked in DESTINATION order here (the
+// blur ring wants a static row phase), so the two horizontally interpolated source rows a destination row blends live in
+// (hA, hB) with their wave-uniform row numbers: a row re-uses them, advances by one source row, or reloads both (scale
+// factors up to 2, and the reflected rows at the top / bottom of the level, which walk backwards).  The source rows of
+// destination row i+1 are requested while row i is computed (PA / PB).
+struct Raw3
+{
+    uint32_t d0, d1, d2;
+};
+struct HRow
+{
+    uint32_t h[4];
+};
+
+// NEED: bit k set = pixel k of a quad may take its (S[x], S[x+1]) pair from window dwords (1,2) instead of (0,1) — a
+// compile-time superset of the level's mask (at scale 1.2 only the fourth pixel ever does), so that the other pixels carry
+// no per-lane selects
+template <bool EXACT, int NEED>
+__global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int n_items = a.n_frames * a.quads;
+    const int R = 6 * a.k6 + 2; // host: R + 6 <= 64 (the block's row table lives in lane registers), R <= dh
+    const int y0 = min((int)blockIdx.y * R, a.dh - R);
+    // lane i keeps the table entry of the block's row i (destination row reflect(y0 - 3 + i)); loaded by ALL lanes before
+    // any leaves (v_readlane reads lanes that have exited, too)
+    const int my_row = reflect_row(y0 - 3 + min(lane, R + 5), a.dh);
+    const int my_y0 = a.yofs[my_row];
+    const uint32_t my_yc = a.ycoef[my_row];
+    if(gw * 62 >= n_items)
+        return; // whole wave beyond the last item (wave-uniform)
+    const int item_raw = gw * 62 - 1 + lane;
+    const bool productive = lane >= 1 && lane <= 62 && item_raw < n_items;
+    const int item = max(0, min(item_raw, n_items - 1));
+    const int f = (int)(((float)item + 0.5f) * a.inv_quads); // item / quads, exact for items < 2^22 (host check)
+    const int qx = item - f * a.quads;
+    const EdgeSel e = edge_selectors(4 * qx, a.dw);
+    const uint4 t0 = a.qt[3 * qx], t1 = a.qt[3 * qx + 1], t2 = a.qt[3 * qx + 2];
+    const uint32_t sel[4] = {t0.z, t0.w, t1.x, t1.y}, coef[4] = {t1.z, t1.w, t2.x, t2.y};
+    const uint32_t src_v = (uint32_t)(f + a.frame0) * a.slab + t0.x;
+    // unconditional stores, halo lanes / halo rows to the slab's dump words: see k_gray_blur
+    const uint32_t dump_v = (uint32_t)(f + a.frame0) * a.slab + a.dump_off + 4u * (uint32_t)lane;
+    const uint32_t pitch_v = productive ? (uint32_t)a.dpitch : 0u;
+    const uint32_t col_v = (uint32_t)(f + a.frame0) * a.slab + (uint32_t)a.dst_off + 4u * (uint32_t)qx;
+    uint32_t raw_v = productive ? col_v + (uint32_t)(y0 - 3) * (uint32_t)a.dpitch : dump_v;
+    uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.dpitch : dump_v;
+    const uint8_t* src_lv = a.pyr + a.src_off;
+
+    auto load = [&](int sy) {
+        const uint8_t* rowp = src_lv + (size_t)sy * (uint32_t)a.spitch; // wave-uniform
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + src_v);
+        return Raw3{p[0], p[1], p[2]};
+    };
+    auto hinterp = [&](const Raw3& w) {
+        HRow r;
+#pragma unroll
+        for(int k = 0; k < 4; ++k)
+        {
+            uint32_t lo = w.d0, hi = w.d1;
+            if(NEED & (1 << k))
+            {
+                const bool up = (t0.y >> k) & 1u;
+                lo = up ? w.d1 : w.d0;
+                hi = up ? w.d2 : w.d1;
+            }
+            const uint32_t pr = __builtin_amdgcn_perm(hi, lo, sel[k]);
+            u16x2_t pv, cv;
+            pv.x = (unsigned short)(pr & 0xFFFF);
+            pv.y = (unsigned short)(pr >> 16);
+            cv.x = (unsigned short)(coef[k] & 0xFFFF);
+            cv.y = (unsigned short)(coef[k] >> 16);
+            r.h[k] = EXACT ? __builtin_amdgcn_udot2(pv, cv, 0u, false) : __builtin_amdgcn_udot2(pv, cv, 0u, false) >> 4;
+        }
+        return r;
+    };
+    // source rows of the block's row i (resizeGeneric_Invoker clips the row index, not the weight)
+    auto rows_of = [&](int i, int& sy0, int& sy1) {
+        const int t = __builtin_amdgcn_readlane(my_y0, i);
+        sy0 = max(0, min(t, a.sh - 1));
+        sy1 = max(0, min(t + 1, a.sh - 1));
+    };
+
+    BlurRing st;
+#pragma unroll
+    for(int j = 0; j < 4; ++j)
+        st.hprev[j] = 0;
+    HRow hA{}, hB{};
+    int rowA = -1, rowB = -1; // wave-uniform: which source rows hA / hB hold
+    // both source rows of every destination row are requested two rows ahead, unconditionally (static 3-deep ring: the
+    // compiler can count its vmcnt waits); whether a row is interpolated again or taken over from hB is decided at use
+    Raw3 RA[3], RB[3];
+#pragma unroll
+    for(int i = 0; i < 2; ++i)
+    {
+        int sy0, sy1;
+        rows_of(i, sy0, sy1);
+        RA[i] = load(sy0);
+        RB[i] = load(sy1);
+    }
+
+    auto row = [&](auto ph, auto emit, auto sraw, int i, bool raw) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr bool EMIT = decltype(emit)::value;
+        constexpr bool SRAW = decltype(sraw)::value; // false for block rows 0 .. 2: no raw store is emitted at all
+        int sy0, sy1;
+        rows_of(i, sy0, sy1);
+        {
+            int ny0, ny1;
+            rows_of(min(i + 2, R + 5), ny0, ny1);
+            RA[(PH + 2) % 3] = load(ny0);
+            RB[(PH + 2) % 3] = load(ny1);
+        }
+        // bring (hA, hB) to (sy0, sy1).  All conditions are wave-uniform; the empty asm statements keep the compiler from
+        // turning the branches into speculated work + selects.
+        const bool reuse = sy1 == rowB && (sy0 == rowA || sy0 == rowB);
+        if(!reuse)
+        {
+            if(sy0 == rowB)
+            {
+                asm volatile("");
+                hA = hB; // one source row further (the common step at scale factors below 2)
+            }
+            else
+            {
+                asm volatile("");
+                hA = hinterp(RA[PH % 3]);
+            }
+            rowA = sy0;
+            if(sy1 == sy0)
+            {
+                asm volatile("");
+                hB = hA; // both clipped to the first / last source row
+            }
+            else
+            {
+                asm volatile("");
+                hB = hinterp(RB[PH % 3]);
+            }
+            rowB = sy1;
+        }
+        const uint32_t yc = (uint32_t)__builtin_amdgcn_readlane((int)my_yc, i);
+        const uint32_t b0 = yc & 0xFFFF, b1 = yc >> 16;
+        auto blend = [&](const HRow& h0, const HRow& h1) {
+            uint32_t r = 0;
+            if(EXACT)
+            {
+                uint32_t acc[4];
+#pragma unroll
+                for(int k = 0; k < 4; ++k) // h <= 65280, weights <= 256: the 24-bit multiply-adds are exact
+                    acc[k] = __umul24(b1, h1.h[k]) + (__umul24(b0, h0.h[k]) + 32768u);
+                r = __builtin_amdgcn_perm(acc[1], acc[0], 0x0C0C0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020C0Cu);
+            }
+            else
+            {
+                const uint32_t b0s = b0 << 16, b1s = b1 << 16; // (b * h) >> 16 as the high half of (b << 16) * h
+                uint32_t v[4];
+#pragma unroll
+                for(int k = 0; k < 4; ++k)
+                    v[k] = (__umulhi(h0.h[k], b0s) + __umulhi(h1.h[k], b1s) + 2u) >> 2; // <= 255
+                r = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0400u) | __builtin_amdgcn_perm(v[3], v[2], 0x04000C0Cu);
+            }
+            return r;
+        };
+        uint32_t g;
+        if(sy0 == rowA)
+        {
+            asm volatile("");
+            g = blend(hA, hB);
+        }
+        else // a re-used pair whose lower row is hB as well (up-scaling only)
+        {
+            asm volatile("");
+            g = blend(hB, hB);
+        }
+        if(SRAW)
+            *reinterpret_cast<uint32_t*>(a.pyr + (raw ? raw_v : dump_v)) = g; // rows 3 .. R+2 need no reflection
+        const uint32_t o = blur_feed<PH, EMIT>(st, g, e, a.bk);
+        if(EMIT)
+            *reinterpret_cast<uint32_t*>(a.blur + blur_v) = o;
+        raw_v += pitch_v;
+        blur_v += pitch_v;
+    };
+    using std::integral_constant;
+#define MSLAM_ROW(PH, EMIT, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, ((PH) >= 3 || (EMIT))>{}, I, RAW)
+    MSLAM_ROW(0, false, 0, false);
+    MSLAM_ROW(1, false, 1, false);
+    MSLAM_ROW(2, false, 2, false);
+    MSLAM_ROW(3, false, 3, true);
+    MSLAM_ROW(4, false, 4, true);
+    MSLAM_ROW(5, false, 5, true);
+#pragma unroll 1
+    for(int i0 = 6; i0 < R + 4; i0 += 6)
+    {
+        MSLAM_ROW(0, true, i0, true);
+        MSLAM_ROW(1, true, i0 + 1, true);
+        MSLAM_ROW(2, true, i0 + 2, true);
+        MSLAM_ROW(3, true, i0 + 3, true);
+        MSLAM_ROW(4, true, i0 + 4, true);
+        MSLAM_ROW(5, true, i0 + 5, i0 + 5 < R + 3);
+    }
+    MSLAM_ROW(0, true, R + 4, false);
+    MSLAM_ROW(1, true, R + 5, false);
+#undef MSLAM_ROW
+}
+
+void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s)
+{
+    const int R = 6 * a.k6 + 2;
+    const int n_waves = (a.n_frames * a.quads + 61) / 62;
+    dim3 grid((n_waves + 3) / 4, (a.dh + R - 1) / R);
+    const int need = (a.need_mask & ~8) == 0 ? (a.need_mask ? 8 : 0) : (a.need_mask & ~12) == 0 ? 12 : 15;
+#define MSLAM_RB(E, N) hipLaunchKernelGGL((k_resize_blur<E, N>), grid, dim3(256), 0, s, a)
+    if(a.exact)
+    {
+        if(need == 0) MSLAM_RB(true, 0); else if(need == 8) MSLAM_RB(true, 8); else if(need == 12) MSLAM_RB(true, 12); else MSLAM_RB(true, 15);
+    }
+    else
+    {
+        if(need == 0) MSLAM_RB(false, 0); else if(need == 8) MSLAM_RB(false, 8); else if(need == 12) MSLAM_RB(false, 12); else MSLAM_RB(false, 15);
+    }
+#undef MSLAM_RB
+}
+
+void launch_gray_blur(const GrayBlurArgs& a, hipStream_t s)
+{
+    const int R = 6 * a.k6 + 2;
+    const int n_waves = (a.n_frames * a.quads + 61) / 62;
+    dim3 grid((n_waves + 3) / 4, (a.H + R - 1) / R);
+    hipLaunchKernelGGL(k_gray_blur, grid, dim3(256), 0, s, a);
+}
+
+} // namespace mslam
