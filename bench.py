@@ -49,6 +49,22 @@ STAGE_KERNEL = {"pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
                 "backproject": "mslam::k_backproject"}
 POPCOUNT_KERNEL = "void mslam::k_match_knn2<8, 1, 8>"
+# kernel name (rocprofv3, without the argument list) -> stage of the step; a stage can be several kernels / launches
+STAGE_PREFIXES = (("mslam::k_gray", "gray"), ("void mslam::k_resize", "resize"), ("mslam::k_resize", "resize"),
+                  ("mslam::k_blur", "blur"), ("mslam::k_fast", "fast"), ("mslam::k_zero_u32", "fast"),
+                  ("mslam::k_quadtree", "quadtree"), ("mslam::k_cv_select", "select"), ("mslam::k_describe", "describe"),
+                  ("void mslam::k_match_knn2", "match_knn2"), ("mslam::k_ratio_compact", "ratio_compact"),
+                  ("mslam::k_backproject", "backproject"), ("mslam::k_pnp_gather", "pnp_gather"),
+                  ("mslam::k_pnp_ransac", "pnp_ransac"), ("mslam::k_bow_descend", "bow_descend"),
+                  ("mslam::k_bow_flat", "bow_descend"), ("mslam::k_bow_vector", "bow_vector"),
+                  ("mslam::k_bow_score", "bow_score"), ("mslam::k_bow_sum", "bow_score"))
+
+
+def stage_of_kernel(name):
+    for pre, st in STAGE_PREFIXES:
+        if name.startswith(pre):
+            return st
+    return None
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_launch.json")
 SQ_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_sq_per_launch.json")
 
@@ -474,13 +490,27 @@ def main():
     # with several ranks a watchdog prints the line without the extras if a collective of the extras never completes
     # (rank 0) / ends the rank quietly (the others).
     watchdog = None
+    line_lock = threading.Lock()
+    printed = [False]
+
+    def emit(line):
+        """exactly one JSON line leaves the process, whoever gets here first (main thread or watchdog)"""
+        with line_lock:
+            if printed[0]:
+                return False
+            printed[0] = True
+            print(json.dumps(line), flush=True)
+            return True
+
     if world > 1:
         def give_up():
-            if rank == 0:
-                line = make_line({"extras_error": "the legs after the timed region did not finish within %d s" % a.extras_timeout},
-                                 with_cpu=False)
-                print(json.dumps(line), flush=True)
-            os._exit(0)
+            # a collective / GPU step of the extras never completed: that is a hang, not a pass.  Rank 0 still prints
+            # the headline (the timed region was complete) with the reason, and EVERY rank exits non-zero.
+            if rank == 0 and not printed[0]:
+                emit(make_line({"extras_error": "the legs after the timed region did not finish within %d s "
+                                                "(hung collective or GPU step): exit code 3" % a.extras_timeout},
+                               with_cpu=False))
+            os._exit(3)
         watchdog = threading.Timer(a.extras_timeout, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -604,17 +634,15 @@ def main():
     except Exception as e:  # noqa: BLE001 - any failure of an extra leg must not cost the headline
         extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
 
+    if watchdog is not None:
+        watchdog.cancel()  # the extras are over: from here on only the main thread builds a line
     out = make_line(extras) if rank == 0 else None
-    try:
-        ctx.close()
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-    finally:
-        if watchdog is not None:
-            watchdog.cancel()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSLAM_HIP_ABI_VERSION 2
+#define MSLAM_HIP_ABI_VERSION 3
 
 enum
 {
@@ -143,6 +143,9 @@ enum
 };
 int mslam_hip_set_matcher(mslam_hip_ctx* ctx, int kind);
 int mslam_hip_get_matcher(const mslam_hip_ctx* ctx);
+/* which kernel the last matcher launch of this context took: 0 = none yet, 1 = matrix cores, 2 = xor/popcount (AUTO decides on
+ * the CAPACITY of the train side: max_keypoints on the batched path, n_from on the host-pointer calls) */
+int mslam_hip_last_match_kernel(const mslam_hip_ctx* ctx);
 
 /* ---- IRelocalizer / ILoopDetector: DBoW3 bag of words ---------------------------------------------
  * Replaces what OrbRelocalizer is wired for (orb_relocalizer.cpp:26-50, relocalizer.hpp:11-20,
@@ -315,8 +318,10 @@ int mslam_hip_level_geometry(mslam_hip_ctx* ctx, int* widths, int* heights, floa
 int mslam_hip_debug_read(mslam_hip_ctx* ctx, int what, int frame, int level, void* dst, size_t dst_bytes,
                          size_t* n_items);
 
-/* Per-(frame, level) counts of the last detect batch: out[n_frames][n_levels] (CANDIDATES or SELECTED). */
-int mslam_hip_debug_counts(mslam_hip_ctx* ctx, int what, int32_t* out);
+/* Per-(frame, level) counts of the last detect batch (CANDIDATES or SELECTED): the first min(n_frames, frames of the
+ * last batch) rows of out[n_frames][n_levels] are written, the rest is left untouched (ABI 3: the row count is an
+ * argument; the call used to copy as many rows as the last batch had, whatever the caller had allocated). */
+int mslam_hip_debug_counts(mslam_hip_ctx* ctx, int what, int32_t* out, int n_frames);
 
 /* Synchronise the context's stream, then copy `bytes` from a device pointer (e.g. out of a view) to host memory. */
 int mslam_hip_copy_to_host(mslam_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);

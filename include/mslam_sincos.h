@@ -13,7 +13,7 @@
 #ifndef MSLAM_SINCOS_H_
 #define MSLAM_SINCOS_H_
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MSLAM_HD __host__ __device__ static inline
 #else
 #include <math.h>

@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "mslam_hip_set_profiling", "mslam_hip_get_stage_times", "mslam_hip_copy_to_host", "mslam_hip_backproject", "mslam_hip_backproject_batch_dev",
     "mslam_hip_get_points_view", "mslam_hip_set_matcher", "mslam_hip_get_matcher",
     "mslam_hip_bow_pack_dev", "mslam_hip_bow_cross_score_packed_dev", "mslam_hip_debug_counts",
+    "mslam_hip_last_match_kernel",
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
     "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size", "mslam_hip_qlz_decompress",
     "mslam_hip_pnp_ransac", "mslam_hip_pnp_batch_dev", "mslam_hip_get_pnp_view",
@@ -205,6 +206,10 @@ class Context:
 
     def get_matcher(self):
         return self.L.mslam_hip_get_matcher(self._h)
+
+    def last_match_kernel(self):
+        """'matrix' / 'popcount': the kernel the last matcher launch took (None before the first)"""
+        return {1: "matrix", 2: "popcount"}.get(self.L.mslam_hip_last_match_kernel(self._h))
 
     def match_knn2(self, from_desc, to_desc):
         f = np.ascontiguousarray(from_desc, np.uint8).reshape(-1, 32)
@@ -383,7 +388,7 @@ class Context:
     def debug_counts(self, what, n_frames):
         """[n_frames, n_levels] FAST candidates (DBG_CANDIDATES) or selected keypoints (DBG_SELECTED) of the last batch"""
         out = np.zeros((max(n_frames, 1), self.params.n_levels), np.int32)
-        self._chk(self.L.mslam_hip_debug_counts(self._h, int(what), _p(out)))
+        self._chk(self.L.mslam_hip_debug_counts(self._h, int(what), _p(out), int(out.shape[0])))
         return out[:n_frames]
 
     def set_profiling(self, enable):

@@ -382,7 +382,8 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
                     c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_to, c->d_hm_out,
                     c->d_xyz, c->d_valid, c->d_pnp_obj, c->d_pnp_img, c->d_pnp_n, c->d_pnp_counts, c->d_pnp_hyp, c->d_pnp_out,
-                    c->d_pnp_mask, c->d_blur_waves};
+                    c->d_pnp_mask, c->d_blur_waves, c->d_pnp1_obj, c->d_pnp1_img, c->d_pnp1_hyp, c->d_pnp1_out,
+                    c->d_pnp1_counts, c->d_pnp1_mask};
     for(void* b : bufs)
         if(b)
             (void)hipFree(b);
@@ -666,7 +667,7 @@ static int create_impl(mslam_hip_ctx* c)
             const char* e = getenv("MSLAM_HIP_FUSED_LEVELS");
             const int want = e ? atoi(e) : kMaxLevels;
             const char* k = getenv("MSLAM_HIP_LEVEL_K6");
-            c->level_k6 = k ? std::max(1, atoi(k)) : 5;
+            c->level_k6 = k ? std::max(1, atoi(k)) : 9; // 9 -> 56-row blocks: the halo re-reads cost 11 % instead of 19 % (32 rows); the step time is the same
             const bool fits = (p.width & 3) == 0 && (double)B * p.width * p.height * 3 < 4294967296.0 &&
                               (double)B * g.slab < 4294967296.0 && (size_t)B * (p.width / 4) < (1u << 22) && p.height >= 8;
             int n_fused = fits ? 1 : 0;
@@ -1259,7 +1260,7 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
         m.dist1 = c->d_dist1 + (size_t)first * K;
         {
             StageScope t(c, "match_knn2", s);
-            launch_match_knn2(m, n_pairs, s);
+            c->last_match_kernel = launch_match_knn2(m, n_pairs, s);
         }
         RatioArgs r{};
         r.idx0 = m.idx0;
@@ -1352,6 +1353,7 @@ int mslam_hip_set_matcher(mslam_hip_ctx* c, int kind)
 }
 
 int mslam_hip_get_matcher(const mslam_hip_ctx* c) { return c ? c->matcher_kind : -1; }
+int mslam_hip_last_match_kernel(const mslam_hip_ctx* c) { return c ? c->last_match_kernel : -1; }
 
 int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,
                          int32_t* idx0, int32_t* idx1, int32_t* dist0, int32_t* dist1)
@@ -1368,7 +1370,7 @@ int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from,
         return rc;
     MatchArgs m;
     host_match_args(c, n_from, n_to, m);
-    launch_match_knn2(m, 1, c->stream);
+    c->last_match_kernel = launch_match_knn2(m, 1, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(idx0, m.idx0, (size_t)n_to * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(idx1, m.idx1, (size_t)n_to * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1398,7 +1400,7 @@ int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, cons
         return rc;
     MatchArgs m;
     host_match_args(c, n_from, n_to, m);
-    launch_match_knn2(m, 1, c->stream);
+    c->last_match_kernel = launch_match_knn2(m, 1, c->stream);
     const size_t cap = (size_t)c->hm_to_cap;
     RatioArgs r{};
     r.idx0 = m.idx0;
@@ -1515,15 +1517,17 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
     return fail(c, MSLAM_HIP_E_INVALID, "debug_read: unknown item");
 }
 
-int mslam_hip_debug_counts(mslam_hip_ctx* c, int what, int32_t* out)
+int mslam_hip_debug_counts(mslam_hip_ctx* c, int what, int32_t* out, int n_frames)
 {
     ENTER(c);
-    if(c->p.width == 0 || !out || (what != MSLAM_HIP_DBG_CANDIDATES && what != MSLAM_HIP_DBG_SELECTED))
+    if(c->p.width == 0 || !out || n_frames < 1 || (what != MSLAM_HIP_DBG_CANDIDATES && what != MSLAM_HIP_DBG_SELECTED))
         return fail(c, MSLAM_HIP_E_INVALID, "debug_counts: bad argument");
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // the scratch arrays are indexed by the frame's position in the batch: [frame][level]
+    // the scratch arrays are indexed by the frame's position in the batch: [frame][level]; never more rows than the
+    // caller has room for
+    const int rows = std::min(n_frames, std::max(c->n_last, 1));
     HIPCHK(c, hipMemcpy(out, what == MSLAM_HIP_DBG_CANDIDATES ? c->quad.cand_cnt : c->quad.sel_cnt,
-                        (size_t)std::max(c->n_last, 1) * c->geom.n_levels * 4, hipMemcpyDeviceToHost));
+                        (size_t)rows * c->geom.n_levels * 4, hipMemcpyDeviceToHost));
     return MSLAM_HIP_OK;
 }
 

@@ -132,6 +132,7 @@ struct GrayBlurArgs
     float inv_quads;
     int k6;             // rows per block = 6 k6 + 2
     unsigned dump_off;  // offset (from the slab's first byte) of the 256 pad bytes that end every frame's slab
+    int waves_per_xcd;  // filled in by the launcher
     BlurK bk;
 };
 void launch_gray_blur(const GrayBlurArgs& a, hipStream_t s);
@@ -152,6 +153,7 @@ struct ResizeBlurArgs
     int need_mask; // bit k: pixel k of some quad takes its pair from dwords (1,2)
     int exact;     // 0: INTER_LINEAR, 1: INTER_LINEAR_EXACT
     unsigned dump_off; // offset of the 256 pad bytes that end every frame's slab
+    int waves_per_xcd; // filled in by the launcher
     BlurK bk;
 };
 void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s);
@@ -244,7 +246,7 @@ struct MatchArgs
     int popcount_only = 0;            // 1: the xor/popcount kernel whatever the train size (mslam_hip_set_matcher)
     int n_pairs = 0, wg_per_pair = 0; // filled in by the launcher
 };
-void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s);
+int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s); // returns the kernel taken: 1 = matrix cores, 2 = xor/popcount
 // ratio test + ordered compaction (orb_feature.cpp:99-114).  thr[d1] = largest d0 accepted + 1.
 struct RatioArgs
 {

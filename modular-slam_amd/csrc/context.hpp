@@ -96,6 +96,7 @@ struct mslam_hip_ctx
     hipStream_t stream_m = nullptr; // matcher stream
     bool overlap_match = true;
     int matcher_kind = 0; // MSLAM_HIP_MATCHER_*
+    int last_match_kernel = 0; // kernel of the last matcher launch: 0 none yet, 1 matrix cores, 2 xor/popcount
     // outputs: slot 0 = last frame of the previous batch, slots 1..max_batch = current batch
     float* d_xy = nullptr;
     uint8_t* d_desc = nullptr;
@@ -123,6 +124,13 @@ struct mslam_hip_ctx
     double *d_pnp_hyp = nullptr, *d_pnp_out = nullptr;
     uint8_t* d_pnp_mask = nullptr;
     int pnp_iterations = 0;
+    // single-problem PnP scratch (mslam_hip_pnp_ransac), grown on demand
+    float *d_pnp1_obj = nullptr, *d_pnp1_img = nullptr;
+    double *d_pnp1_hyp = nullptr, *d_pnp1_out = nullptr;
+    int32_t* d_pnp1_counts = nullptr;
+    uint8_t* d_pnp1_mask = nullptr;
+    int pnp1_n_cap = 0, pnp1_it_cap = 0;
+    bool pnp_attr_set = false; // the > 64 KB dynamic-LDS attribute of the PnP kernels, per context (= per device)
 
     mslam::BowState* bow = nullptr;
 

@@ -18,6 +18,7 @@
 #include "context.hpp"
 
 #include <algorithm>
+#include <new>
 #include <cmath>
 #include <cstring>
 
@@ -1344,7 +1345,14 @@ int mslam_hip_bow_load(mslam_hip_ctx* c, const void* blob, size_t size)
     BHIPCHK(c, hipSetDevice(c->p.device));
     if(hipStreamSynchronize(c->stream) != hipSuccess)
         return bfail(c, MSLAM_HIP_E_RUNTIME, "bow_load: stream sync failed");
-    return bow_load_impl(c, blob, size);
+    try
+    {
+        return bow_load_impl(c, blob, size);
+    }
+    catch(const std::bad_alloc&) // an untrusted header can ask for more host memory than there is: no exception crosses the C ABI
+    {
+        return bfail(c, MSLAM_HIP_E_RUNTIME, "bow_load: out of host memory while decoding the vocabulary");
+    }
 }
 
 int mslam_hip_bow_info(mslam_hip_ctx* c, int* k, int* L, int* n_nodes, int* n_words, int* scoring, int* weighting)

@@ -156,7 +156,10 @@ struct Bgr3
 __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    // XCD-aware wave numbering: workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is a multiple of 8, so the
+    // XCD of a workgroup is blockIdx.x & 7 for every row block).  Each XCD gets a contiguous eighth of the waves: waves that
+    // are neighbours in the image (shared 128-byte lines at their edges, shared halo rows between row blocks) meet in one L2.
+    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x & 7) * a.waves_per_xcd + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)));
     const int n_items = a.n_frames * a.quads;
     const int item_raw = gw * 62 - 1 + lane;
     if(gw * 62 >= n_items)
@@ -211,27 +214,27 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
         blur_v += pitch_v;
     };
     using std::integral_constant;
-#define MSLAM_ROW(PH, EMIT, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, ((PH) >= 3 || (EMIT))>{}, I, RAW)
+#define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
     // rows 0 .. 5: fill the ring (rows 3, 4, 5 are the block's first rows)
-    MSLAM_ROW(0, false, 0, false);
-    MSLAM_ROW(1, false, 1, false);
-    MSLAM_ROW(2, false, 2, false);
-    MSLAM_ROW(3, false, 3, true);
-    MSLAM_ROW(4, false, 4, true);
-    MSLAM_ROW(5, false, 5, true);
+    MSLAM_ROW(0, false, false, 0, false);
+    MSLAM_ROW(1, false, false, 1, false);
+    MSLAM_ROW(2, false, false, 2, false);
+    MSLAM_ROW(3, false, true, 3, true);
+    MSLAM_ROW(4, false, true, 4, true);
+    MSLAM_ROW(5, false, true, 5, true);
 #pragma unroll 1
     for(int i0 = 6; i0 < R + 4; i0 += 6)
     {
-        MSLAM_ROW(0, true, i0, true);
-        MSLAM_ROW(1, true, i0 + 1, true);
-        MSLAM_ROW(2, true, i0 + 2, true);
-        MSLAM_ROW(3, true, i0 + 3, true);
-        MSLAM_ROW(4, true, i0 + 4, true);
-        MSLAM_ROW(5, true, i0 + 5, i0 + 5 < R + 3);
+        MSLAM_ROW(0, true, true, i0, true);
+        MSLAM_ROW(1, true, true, i0 + 1, true);
+        MSLAM_ROW(2, true, true, i0 + 2, true);
+        MSLAM_ROW(3, true, true, i0 + 3, true);
+        MSLAM_ROW(4, true, true, i0 + 4, true);
+        MSLAM_ROW(5, true, true, i0 + 5, i0 + 5 < R + 3); // the block's last raw row is R + 2: in the last trip this one is a halo row
     }
     // rows R+4, R+5 (R + 4 = 6 (k6 + 1)): halo rows below the block
-    MSLAM_ROW(0, true, R + 4, false);
-    MSLAM_ROW(1, true, R + 5, false);
+    MSLAM_ROW(0, true, false, R + 4, false);
+    MSLAM_ROW(1, true, false, R + 5, false);
 #undef MSLAM_ROW
 }
 
@@ -258,7 +261,10 @@ template <bool EXACT, int NEED>
 __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    // XCD-aware wave numbering: workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is a multiple of 8, so the
+    // XCD of a workgroup is blockIdx.x & 7 for every row block).  Each XCD gets a contiguous eighth of the waves: waves that
+    // are neighbours in the image (shared 128-byte lines at their edges, shared halo rows between row blocks) meet in one L2.
+    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x & 7) * a.waves_per_xcd + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)));
     const int n_items = a.n_frames * a.quads;
     const int R = 6 * a.k6 + 2; // host: R + 6 <= 64 (the block's row table lives in lane registers), R <= dh
     const int y0 = min((int)blockIdx.y * R, a.dh - R);
@@ -421,25 +427,25 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
         blur_v += pitch_v;
     };
     using std::integral_constant;
-#define MSLAM_ROW(PH, EMIT, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, ((PH) >= 3 || (EMIT))>{}, I, RAW)
-    MSLAM_ROW(0, false, 0, false);
-    MSLAM_ROW(1, false, 1, false);
-    MSLAM_ROW(2, false, 2, false);
-    MSLAM_ROW(3, false, 3, true);
-    MSLAM_ROW(4, false, 4, true);
-    MSLAM_ROW(5, false, 5, true);
+#define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
+    MSLAM_ROW(0, false, false, 0, false);
+    MSLAM_ROW(1, false, false, 1, false);
+    MSLAM_ROW(2, false, false, 2, false);
+    MSLAM_ROW(3, false, true, 3, true);
+    MSLAM_ROW(4, false, true, 4, true);
+    MSLAM_ROW(5, false, true, 5, true);
 #pragma unroll 1
     for(int i0 = 6; i0 < R + 4; i0 += 6)
     {
-        MSLAM_ROW(0, true, i0, true);
-        MSLAM_ROW(1, true, i0 + 1, true);
-        MSLAM_ROW(2, true, i0 + 2, true);
-        MSLAM_ROW(3, true, i0 + 3, true);
-        MSLAM_ROW(4, true, i0 + 4, true);
-        MSLAM_ROW(5, true, i0 + 5, i0 + 5 < R + 3);
+        MSLAM_ROW(0, true, true, i0, true);
+        MSLAM_ROW(1, true, true, i0 + 1, true);
+        MSLAM_ROW(2, true, true, i0 + 2, true);
+        MSLAM_ROW(3, true, true, i0 + 3, true);
+        MSLAM_ROW(4, true, true, i0 + 4, true);
+        MSLAM_ROW(5, true, true, i0 + 5, i0 + 5 < R + 3); // the block's last raw row is R + 2: in the last trip this one is a halo row
     }
-    MSLAM_ROW(0, true, R + 4, false);
-    MSLAM_ROW(1, true, R + 5, false);
+    MSLAM_ROW(0, true, false, R + 4, false);
+    MSLAM_ROW(1, true, false, R + 5, false);
 #undef MSLAM_ROW
 }
 
@@ -447,9 +453,11 @@ void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s)
 {
     const int R = 6 * a.k6 + 2;
     const int n_waves = (a.n_frames * a.quads + 61) / 62;
-    dim3 grid((n_waves + 3) / 4, (a.dh + R - 1) / R);
+    ResizeBlurArgs b = a;
+    b.waves_per_xcd = ((n_waves + 31) / 32) * 4; // whole workgroups per XCD
+    dim3 grid(8 * (b.waves_per_xcd / 4), (a.dh + R - 1) / R);
     const int need = (a.need_mask & ~8) == 0 ? (a.need_mask ? 8 : 0) : (a.need_mask & ~12) == 0 ? 12 : 15;
-#define MSLAM_RB(E, N) hipLaunchKernelGGL((k_resize_blur<E, N>), grid, dim3(256), 0, s, a)
+#define MSLAM_RB(E, N) hipLaunchKernelGGL((k_resize_blur<E, N>), grid, dim3(256), 0, s, b)
     if(a.exact)
     {
         if(need == 0) MSLAM_RB(true, 0); else if(need == 8) MSLAM_RB(true, 8); else if(need == 12) MSLAM_RB(true, 12); else MSLAM_RB(true, 15);
@@ -465,8 +473,10 @@ void launch_gray_blur(const GrayBlurArgs& a, hipStream_t s)
 {
     const int R = 6 * a.k6 + 2;
     const int n_waves = (a.n_frames * a.quads + 61) / 62;
-    dim3 grid((n_waves + 3) / 4, (a.H + R - 1) / R);
-    hipLaunchKernelGGL(k_gray_blur, grid, dim3(256), 0, s, a);
+    GrayBlurArgs b = a;
+    b.waves_per_xcd = ((n_waves + 31) / 32) * 4; // whole workgroups per XCD
+    dim3 grid(8 * (b.waves_per_xcd / 4), (a.H + R - 1) / R);
+    hipLaunchKernelGGL(k_gray_blur, grid, dim3(256), 0, s, b);
 }
 
 } // namespace mslam

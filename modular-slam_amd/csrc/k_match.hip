@@ -383,7 +383,7 @@ static void launch_fp4(MatchArgs a, int n_pairs, hipStream_t s)
     hipLaunchKernelGGL((k_match_knn2_fp4<QT>), dim3(grid), dim3(256), 0, s, a);
 }
 
-void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
+int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
 {
     // matrix-core kernel (4 query tiles per wave: 0.117 ms per 250 x 1900^2 pairs against 0.48 ms for the
     // VALU kernel) whenever the train side fits its 14-bit age field; the VALU kernel otherwise
@@ -393,8 +393,12 @@ void launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
     // 0.12 ms per 250 x 1900^2 pairs)
     const int max_train = a.from_cnt ? a.cap_from : a.n_from_fixed;
     if(max_train <= MM_MAX_TRAIN && !a.popcount_only)
-        return launch_fp4<4>(a, n_pairs, s);
+    {
+        launch_fp4<4>(a, n_pairs, s);
+        return 1;
+    }
     launch_variant<8, 1, 8>(a, n_pairs, s);
+    return 2;
 }
 
 // ratio test (orb_feature.cpp:99-105) + ordered compaction (:110-114); one workgroup per pair

@@ -779,6 +779,19 @@ static void R_to_rodrigues(const double R[9], double r[3])
     r[0] = th * k[0], r[1] = th * k[1], r[2] = th * k[2];
 }
 
+// both kernels take more than 64 KB of dynamic LDS: the attribute belongs to the (function, device) pair, so it is set once
+// per CONTEXT (after hipSetDevice), not once per process
+static hipError_t pnp_lds_attributes(mslam_hip_ctx* c, size_t lds)
+{
+    if(c->pnp_attr_set)
+        return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if(e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    c->pnp_attr_set = e == hipSuccess;
+    return e;
+}
+
 extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points, const float* image_points, int n, double fx,
                                     double fy, double cx, double cy, int use_extrinsic_guess, int iterations,
                                     double reprojection_error, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers,
@@ -796,25 +809,37 @@ extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points
     if(n_inliers)
         *n_inliers = 0;
     hipError_t e = hipSetDevice(c->p.device);
-    float *d_obj = nullptr, *d_img = nullptr;
-    double *d_hyp = nullptr, *d_out = nullptr;
-    int32_t* d_counts = nullptr;
-    uint8_t* d_mask = nullptr;
-    auto cleanup = [&]() {
-        void* bufs[] = {d_obj, d_img, d_hyp, d_out, d_counts, d_mask};
-        for(void* b : bufs)
-            if(b)
-                (void)hipFree(b);
-    };
 #define PCHK(call)                                                                                                     \
     if(e == hipSuccess)                                                                                                \
     e = (call)
-    PCHK(hipMalloc(reinterpret_cast<void**>(&d_obj), (size_t)n * 12));
-    PCHK(hipMalloc(reinterpret_cast<void**>(&d_img), (size_t)n * 8));
-    PCHK(hipMalloc(reinterpret_cast<void**>(&d_hyp), (size_t)iterations * 12 * 8));
-    PCHK(hipMalloc(reinterpret_cast<void**>(&d_out), 16 * 8));
-    PCHK(hipMalloc(reinterpret_cast<void**>(&d_counts), (size_t)iterations * 4));
-    PCHK(hipMalloc(reinterpret_cast<void**>(&d_mask), (size_t)n));
+    // scratch of the single-problem call lives in the context and only grows (this is the per-frame tracking path of the
+    // plugin: six hipMalloc + six hipFree, each a device synchronisation, per call would cost more than the solve)
+    if(n > c->pnp1_n_cap || iterations > c->pnp1_it_cap)
+    {
+        PCHK(hipStreamSynchronize(c->stream));
+        void* old[] = {c->d_pnp1_obj, c->d_pnp1_img, c->d_pnp1_hyp, c->d_pnp1_out, c->d_pnp1_counts, c->d_pnp1_mask};
+        for(void* b : old)
+            if(b)
+                (void)hipFree(b);
+        c->d_pnp1_obj = c->d_pnp1_img = nullptr;
+        c->d_pnp1_hyp = c->d_pnp1_out = nullptr;
+        c->d_pnp1_counts = nullptr;
+        c->d_pnp1_mask = nullptr;
+        c->pnp1_n_cap = c->pnp1_it_cap = 0;
+        const int n_cap = std::max(n, 1024), it_cap = std::max(iterations, 128);
+        PCHK(hipMalloc(reinterpret_cast<void**>(&c->d_pnp1_obj), (size_t)n_cap * 12));
+        PCHK(hipMalloc(reinterpret_cast<void**>(&c->d_pnp1_img), (size_t)n_cap * 8));
+        PCHK(hipMalloc(reinterpret_cast<void**>(&c->d_pnp1_hyp), (size_t)it_cap * 12 * 8));
+        PCHK(hipMalloc(reinterpret_cast<void**>(&c->d_pnp1_out), 16 * 8));
+        PCHK(hipMalloc(reinterpret_cast<void**>(&c->d_pnp1_counts), (size_t)it_cap * 4));
+        PCHK(hipMalloc(reinterpret_cast<void**>(&c->d_pnp1_mask), (size_t)n_cap));
+        if(e == hipSuccess)
+            c->pnp1_n_cap = n_cap, c->pnp1_it_cap = it_cap;
+    }
+    float *d_obj = c->d_pnp1_obj, *d_img = c->d_pnp1_img;
+    double *d_hyp = c->d_pnp1_hyp, *d_out = c->d_pnp1_out;
+    int32_t* d_counts = c->d_pnp1_counts;
+    uint8_t* d_mask = c->d_pnp1_mask;
     PCHK(hipMemcpyAsync(d_obj, object_points, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
     PCHK(hipMemcpyAsync(d_img, image_points, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     PnpArgs a{};
@@ -828,7 +853,7 @@ extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points
     a.seed = seed;
     a.hyp = d_hyp, a.counts = d_counts, a.mask = d_mask, a.out = d_out;
     const size_t lds = (size_t)kPnpRed * 8 + (size_t)kPnpLdsHyp * (96 + 4) + (size_t)kPnpLdsPts * 21;
-    PCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PCHK(pnp_lds_attributes(c, lds));
     if(e == hipSuccess)
         hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(kPnpThreads), lds, c->stream, a);
     PCHK(hipGetLastError());
@@ -838,7 +863,6 @@ extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points
     PCHK(hipMemcpyAsync(mask.data(), d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     PCHK(hipStreamSynchronize(c->stream));
 #undef PCHK
-    cleanup();
     if(e != hipSuccess)
     {
         c->err = std::string("pnp_ransac: ") + hipGetErrorString(e);
@@ -924,9 +948,7 @@ extern "C" int mslam_hip_pnp_batch_dev(mslam_hip_ctx* c, double fx, double fy, d
     b.n = c->d_pnp_n;
     b.cap = K;
     const size_t lds = (size_t)kPnpRed * 8 + (size_t)kPnpLdsHyp * (96 + 4) + (size_t)kPnpLdsPts * 21;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac_batch),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if(attr != hipSuccess)
+    if(pnp_lds_attributes(c, lds) != hipSuccess)
         return fail(MSLAM_HIP_E_RUNTIME, "pnp_batch_dev: hipFuncSetAttribute");
     {
         StageScope t(c, "pnp_ransac");

@@ -23,6 +23,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <vector>
 
 namespace
@@ -186,7 +187,13 @@ int qlz_decode_stream(const uint8_t* src, size_t size, uint32_t n_packets, std::
         const int n = (src[pos] & 2) ? 4 : 1;
         if(size - pos < (size_t)(2 * n + 1))
             return MSLAM_HIP_E_FORMAT;
+        // the header is untrusted: bound both sizes before anything is allocated.  A match token is at least one input
+        // byte and yields at most 258 output bytes (decode_packet), so no valid packet has dsize > 258 * csize; the whole
+        // stream is capped at 4 GiB.
+        const size_t csize = rd(src + pos + 1, src + size, n);
         const size_t dsize = rd(src + pos + 1 + n, src + size, n);
+        if(csize < (size_t)(2 * n + 1) || csize > size - pos || dsize > csize * 258 || out.size() + dsize > (size_t)1 << 32)
+            return MSLAM_HIP_E_FORMAT;
         const size_t at = out.size();
         out.resize(at + dsize + 4); // + 4: the level-1 hash update reads two bytes past a position
         size_t consumed = 0, produced = 0;
@@ -206,7 +213,15 @@ extern "C" int mslam_hip_qlz_decompress(const void* src, size_t src_size, uint32
     if(!src || !dst_size)
         return MSLAM_HIP_E_INVALID;
     std::vector<uint8_t> out;
-    const int rc = mslam::qlz_decode_stream(static_cast<const uint8_t*>(src), src_size, n_packets, out);
+    int rc;
+    try
+    {
+        rc = mslam::qlz_decode_stream(static_cast<const uint8_t*>(src), src_size, n_packets, out);
+    }
+    catch(const std::bad_alloc&) // no C++ exception crosses the C ABI
+    {
+        return MSLAM_HIP_E_RUNTIME;
+    }
     if(rc)
         return rc;
     *dst_size = out.size();

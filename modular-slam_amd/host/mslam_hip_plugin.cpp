@@ -360,17 +360,17 @@ class HipRansacPnp : public ISlam3dPnp
   private:
     static void toRodrigues(double w, double x, double y, double z, double r[3])
     {
-        // Eigen::AngleAxisd(q): angle = 2 atan2(|v|, |w|), axis = v / |v| (sign folded for w < 0)
-        double nv = std::sqrt(x * x + y * y + z * z);
+        // Eigen::AngleAxisd(q) (cv_ransac_pnp.cpp:44-48): angle = 2 atan2(|v|, |w|) from the POSITIVE norm, then the axis is
+        // v / |v| for w >= 0 and -v / |v| for w < 0 (q and -q are the same rotation)
+        const double nv = std::sqrt(x * x + y * y + z * z);
         if(nv < 1e-300)
         {
             r[0] = r[1] = r[2] = 0;
             return;
         }
-        if(w < 0)
-            nv = -nv;
         const double angle = 2.0 * std::atan2(nv, std::fabs(w));
-        r[0] = x / nv * angle, r[1] = y / nv * angle, r[2] = z / nv * angle;
+        const double d = w < 0 ? -nv : nv;
+        r[0] = x / d * angle, r[1] = y / d * angle, r[2] = z / d * angle;
     }
     Ctx ctx;
     std::vector<float> obj, img;

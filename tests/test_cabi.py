@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.lib()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.mslam_hip_abi_version() == 2   # 2: mslam_hip_params gained detector / n_features / edge_threshold
+    assert lib.mslam_hip_abi_version() == 3   # 2: mslam_hip_params gained detector / n_features / edge_threshold; 3: debug_counts takes its row count
 
 
 def test_default_params_are_the_reference_operating_point(pkg):

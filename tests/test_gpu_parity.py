@@ -219,6 +219,40 @@ def test_batch_device_path(pkg, orc, synth_frames, matcher):
     c.close()
 
 
+def test_batch_matcher_auto_switch_on_capacity(pkg, orc, synth_frames):
+    """MATCHER_AUTO on the batched path: a context whose max_keypoints exceeds the matrix-core kernel's train range
+    (32 736 rows: the 14-bit age field of its sort key) must take the xor/popcount kernel (k_match.hip:
+    launch_match_knn2 decides on the CAPACITY, cap_from, not on the actual counts) and still match the oracle."""
+    import torch
+    frames = synth_frames[:3]
+    dev = torch.from_numpy(frames).cuda()
+    c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=40000)
+    assert c.get_matcher() == pkg.MATCHER_AUTO
+    c.set_profiling(1)
+    c.detect_batch_dev(dev.data_ptr(), 3)
+    c.match_batch_dev(0.7, True)
+    c.sync()
+    c.set_profiling(0)
+    v = c.batch_view()
+    K = v.capacity
+    assert K == 40000
+    refs = [orc.detect(f, orc.params()) for f in frames]
+    mc = pkg.read_device(c, v.match_count, (3,), np.int32)
+    mf = pkg.read_device(c, v.match_from, (3, K), np.int32)
+    mt = pkg.read_device(c, v.match_to, (3, K), np.int32)
+    for t in (1, 2):
+        rf, rt = orc.match(refs[t]["desc"], refs[t - 1]["desc"])
+        assert mc[t] == len(rf) and np.array_equal(mf[t, :mc[t]], rf) and np.array_equal(mt[t, :mc[t]], rt)
+    assert c.last_match_kernel() == "popcount"
+    c.close()
+    c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=4096)
+    c.detect_batch_dev(dev.data_ptr(), 3)
+    c.match_batch_dev(0.7, True)
+    c.sync()
+    assert c.last_match_kernel() == "matrix"
+    c.close()
+
+
 def test_backproject_rgbd(pkg, orc, ctx, bundled_frames, bundled_depth):
     """row f-1: depth lookup + pin-hole back-projection of the detected keypoints (TUM intrinsics)"""
     det = orc.detect(bundled_frames[0], orc.params())

@@ -142,9 +142,12 @@ def test_plugin_cv_orb_detector(built, orc, bundled_frames, tmp_path):
 
 
 @pytest.mark.gpu
-def test_plugin_pnp(built, tmp_path):
+@pytest.mark.parametrize("negative_w", [False, True])
+def test_plugin_pnp(built, tmp_path, negative_w):
     """hipRansacPnpFactory: the OpenCvRansacPnp drop-in (cv_ransac_pnp.cpp:14-85) through the loader — sensor pose in,
-    sensor pose out (the adapter does the world->camera inversions of :42-50 and :65-78 around the solver)"""
+    sensor pose out (the adapter does the world->camera inversions of :42-50 and :65-78 around the solver).  The initial
+    orientation is also passed as -q (w < 0: the same rotation; Eigen::AngleAxisd folds the sign into the axis,
+    cv_ransac_pnp.cpp:44-48): the extrinsic guess, and so the result, must not change."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mslam_pnp_oracle as po
@@ -164,7 +167,7 @@ def test_plugin_pnp(built, tmp_path):
         f.write(struct.pack("<I", len(obj)))
         for P, uv in zip(obj.astype(np.float64), img.astype(np.float64)):
             f.write(struct.pack("<5d", *P, *uv))
-        f.write(struct.pack("<7d", *p0s, *quat(R0s)))
+        f.write(struct.pack("<7d", *p0s, *(-quat(R0s) if negative_w else quat(R0s))))
         f.write(struct.pack("<4d", *CAM))
     r = subprocess.run([HARNESS, PLUGIN, "--pnp", str(path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
