@@ -44,8 +44,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md, matrix cores)
-STAGE_KERNEL = {"pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "mslam::k_gray4", "resize": "void mslam::k_resize_col<false>", "fast": "mslam::k_fast_cells",
-                "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur", "describe": "mslam::k_describe",
+STAGE_KERNEL = {"pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "mslam::k_gray_blur",
+                "resize": "void mslam::k_resize_blur<false, N> (one launch per level)", "fast": "mslam::k_fast_cells",
+                "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur2", "describe": "mslam::k_describe",
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
                 "backproject": "mslam::k_backproject"}
 POPCOUNT_KERNEL = "void mslam::k_match_knn2<8, 1, 8>"
@@ -65,8 +66,8 @@ def stage_of_kernel(name):
         if name.startswith(pre):
             return st
     return None
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_per_launch.json")
-SQ_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_sq_per_launch.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_per_step.json")  # tools/summarize_counters.py
+CLOCK_HZ = 2.4e9  # MI355X max shader clock (MI355X_MICROARCH.md); the vector-ALU issue figures are quoted at this clock
 
 
 def csrc_sha():
@@ -79,40 +80,42 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel, kernels_per_launch, frames_per_launch):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected in
-    separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced streaming reads —
-    MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known input confirms).  Returns
-    (bytes or None, note): None when no profile is committed or it was taken on other kernel sources."""
+def pmc_profile():
+    """(per-stage counter totals per step, frames per step, note): the committed rocprofv3 PMC passes, or (None, ..)
+    with the reason when there is none or it was taken on other kernel sources"""
     try:
         j = json.load(open(PMC_PROFILE))
         meta = j["_meta"]
-        d = j[kernel]
-        fpl = meta["frames_per_launch"]
-        scale = frames_per_launch / float(fpl.get(kernel, fpl["default"]))  # traffic is linear in the batch size
     except (OSError, KeyError, ValueError):
-        return None, "no PMC profile committed for this kernel (%s)" % os.path.basename(PMC_PROFILE)
+        return None, 1000, "no PMC profile committed (%s)" % os.path.basename(PMC_PROFILE)
     if meta.get("csrc_sha") != csrc_sha():
-        return None, "stale: %s was collected on kernel sources %s, this build is %s" % (
+        return None, 1000, "stale: %s was collected on kernel sources %s, this build is %s" % (
             os.path.basename(PMC_PROFILE), meta.get("csrc_sha"), csrc_sha())
-    return (int((2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024 * scale * kernels_per_launch),
-            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH + WRITE) KB per launch, %s" %
-            os.path.basename(PMC_PROFILE))
+    return j["stages"], float(meta.get("frames_per_step", 1000)), (
+        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes), summed over the launches of a step, "
+        "(2*FETCH + WRITE) KB, %s" % os.path.basename(PMC_PROFILE))
 
 
-def valu_fraction(kernel, avg_ms, frames_per_launch):
-    """vector-ALU issue time of the kernel / its duration, from the committed SQ pass (SQ_INSTS_VALU x 4 cycles over
-    1024 SIMDs at 2.4 GHz); None when not available for these sources"""
-    try:
-        j = json.load(open(SQ_PROFILE))
-        if j["_meta"].get("csrc_sha") != csrc_sha():
-            return None
-        fpl = j["_meta"]["frames_per_launch"]
-        scale = frames_per_launch / float(fpl.get(kernel, fpl["default"]))
-        insts = j[kernel]["SQ_INSTS_VALU"] * scale
-    except (OSError, KeyError, ValueError):
+def pmc_traffic(stage, frames_per_step):
+    """HBM-side bytes per STEP of a stage from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are collected in
+    separate runs, in KB; on gfx950 FETCH_SIZE counts half of the bytes of coalesced streaming reads —
+    MI355X_MICROARCH.md §HBM — hence the factor 2, which the gray kernel's known input confirms)."""
+    st, fps, note = pmc_profile()
+    if st is None or stage not in st or "FETCH_SIZE" not in st[stage]:
+        return None, note
+    d = st[stage]
+    return int((2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024 * frames_per_step / fps), note
+
+
+def valu_issue_ms(stage, frames_per_step):
+    """vector-ALU issue time of a stage per step: SQ_INSTS_VALU x 4 cycles over 1024 SIMDs at 2.4 GHz (None when there is
+    no valid profile).  stage = None: the whole step."""
+    st, fps, _ = pmc_profile()
+    if st is None:
         return None
-    return insts * 4 / (1024 * 2.4e9) / (avg_ms * 1e-3)
+    names = [stage] if stage else list(st)
+    tot = sum(st[n].get("SQ_INSTS_VALU", 0.0) for n in names if n in st)
+    return tot * 4 / (1024 * CLOCK_HZ) * 1e3 * frames_per_step / fps
 
 
 def baseline_metric():
@@ -150,6 +153,8 @@ def parse():
     ap.add_argument("--extras-timeout", type=int, default=300,
                     help="with several ranks: seconds the legs after the timed region may take before rank 0 prints "
                          "the line without them")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the cfg3 / cfg5 / single-frame-latency legs that follow the timed region of the default run")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs after the timed region (popcount matcher, serialized stages, PCIe-inclusive, "
                          "exchange): what the profiling passes use")
@@ -176,8 +181,10 @@ def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
     px = [a * b for a, b in zip(w, h)]
     P = sum(px)
     return {
-        "gray": B * (3 * px[0] + px[0]),
-        "resize": B * sum(px[l - 1] + px[l] for l in range(1, len(px))),
+        # level kernels (k_level.hip): gray + blur writes level 0 twice (raw, blurred); resize + blur reads level l-1 and
+        # writes level l twice
+        "gray": B * (3 * px[0] + 2 * px[0]),
+        "resize": B * sum(px[l - 1] + 2 * px[l] for l in range(1, len(px))),
         "fast": B * P + 4 * n_cand,
         "quadtree": 4 * n_cand + 4 * n_kp,
         "blur": B * 2 * P,
@@ -244,15 +251,32 @@ def dry_run(a, rank, world):
         dist.init_process_group("gloo")
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     k = torch.tensor([100.0], dtype=torch.float64)
+    exchange = None
     if world > 1:
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        # the loop-candidate exchange of the real run, on host tensors of the real shape: ONE all_gather_into_tensor of
+        # the rank's packed BoW set per batch (modular_slam_amd/multi_stream.py), here 3 batches of 8 frames
+        import __graft_entry__ as graft
+        graft.load_package()
+        from modular_slam_amd.multi_stream import CrossStreamLoopCandidates, set_dwords
+        cross = CrossStreamLoopCandidates(k_max=2048)
+        n_b, fr = 3, 8
+        for b in range(n_b):
+            local = torch.full((set_dwords(fr, cross.k_max),), rank * 1000 + b, dtype=torch.int32)
+            got = cross.all_gather_sets(local)
+            assert got.shape[0] == world and all(int(got[r].view(-1)[0]) == r * 1000 + b for r in range(world))
+        exchange = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                    "collectives_per_batch": cross.collectives / float(n_b), "bytes_per_rank_per_batch": 4 * set_dwords(fr, cross.k_max)}
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "dist": {"backend": "gloo" if world > 1 else None, "world_size": world,
-                                   "launched_by": os.environ.get("MSLAM_BENCH_LAUNCHER", "external")},
-                          "t_max": float(t.item()), "units": float(k.item())}))
+        line = {"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "dist": {"backend": "gloo" if world > 1 else None, "world_size": world,
+                         "launched_by": os.environ.get("MSLAM_BENCH_LAUNCHER", "external")},
+                "t_max": float(t.item()), "units": float(k.item())}
+        if exchange is not None:
+            line["exchange"] = exchange
+        print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -305,7 +329,8 @@ def main():
     ts = torch.cuda.Stream()  # the context's stream is a torch stream: torch copies / collectives order against it
     cv = a.detector == "cvorb"
     if cv:
-        STAGE_KERNEL.update({"resize": "void mslam::k_resize_col<true>", "fast": "mslam::k_fast_tiles", "select": "mslam::k_cv_select"})
+        STAGE_KERNEL.update({"resize": "void mslam::k_resize_blur<true, N> (one launch per level)", "fast": "mslam::k_fast_tiles",
+                             "select": "mslam::k_cv_select"})
     ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=a.min_area,
                       max_keypoints=min(32736, max(4096 * k_scale, 2 * a.n_features if cv else 0)),  # 32736: the matrix-core matcher's train range
                       max_candidates=16384 * area, device=dev, stream=ts.cuda_stream,
@@ -315,6 +340,10 @@ def main():
     need_voc = a.bow or (world > 1 and not a.no_extras)
     if need_voc:
         ctx.bow_load(synth.make_vocabulary(10, a.voc_levels, seed=77))
+        if a.bow:
+            # every step adds a batch of entries to the inverted file: reserve them, so that no storage doubling (a
+            # reallocation + copy of the posting log) falls into the timed steps
+            ctx.bow_db_reserve((max(a.warmup, n_batches) + 3 * a.steps + 16) * B)
         cross = CrossStreamLoopCandidates(k_max=2048 * k_scale)
 
     def step(i, bow=a.bow):
@@ -403,28 +432,52 @@ def main():
         bytes_per_launch = sb[dom] / per_step[dom]
         achieved = bytes_per_launch / (avg[dom] * 1e-3) / 1e9
         kern = STAGE_KERNEL.get(dom, dom)
-        traffic, traffic_note = pmc_traffic(kern, 7 if dom == "resize" else 1, fpl)
+        traffic_step, traffic_note = pmc_traffic(dom, B)
+        traffic = int(traffic_step / per_step[dom]) if traffic_step is not None else None
         # the kernel's own duration: alone on the GPU when the serialized pass ran (in place it shares the GPU with
         # the sibling chunk's kernels, which would halve the fraction)
         ser = extras.get("stages_ms_serialized", {})
-        alone_ms = ser[dom] / per_step[dom] if dom in ser else None
-        vfrac = valu_fraction(kern, alone_ms if alone_ms else avg[dom], fpl)
-        roofline = {"kernel": kern, "stage": dom, "bound": "hbm", "achieved": round(achieved, 1),
+        alone_step_ms = ser.get(dom)                                # ms per step with every launch of the stage alone
+        frac_alone = (sb[dom] / (alone_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_step_ms else None
+        v_ms = valu_issue_ms(dom, B)
+        valu_frac_alone = (v_ms / alone_step_ms) if (v_ms is not None and alone_step_ms) else None
+        step_valu = valu_issue_ms(None, B)
+        step_ms = dt_max / a.steps * 1e3
+        # what binds the dominant kernel: the larger of its HBM fraction and its vector-ALU issue fraction (both alone)
+        bound = "hbm"
+        if valu_frac_alone is not None and frac_alone is not None and valu_frac_alone > frac_alone:
+            bound = "valu"
+        limiter = "not HBM (see DESIGN.md §4: every stage but gray is issue- or latency-bound)"
+        if valu_frac_alone is not None:
+            limiter = ("vector-ALU issue %.0f %% of the kernel's duration alone on the GPU (SQ_INSTS_VALU x 4 cycles at 2.4 GHz, "
+                       "%s) against %.0f %% of the HBM peak for its algorithmic bytes" % (
+                           100 * valu_frac_alone, os.path.basename(PMC_PROFILE), 100 * frac_alone))
+            if dom == "describe":
+                limiter += "; the rest of its time is the L2 -> LDS window gathers (DESIGN.md §4.6)"
+        roofline = {"kernel": kern, "stage": dom, "bound": bound, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "frac_alone": round(frac_alone, 4) if frac_alone is not None else None,
+                    "valu_issue_frac_alone": round(valu_frac_alone, 3) if valu_frac_alone is not None else None,
+                    # the roofline that binds the STEP: vector-ALU issue time of all its kernels / the step time
+                    "step_valu_issue": round(step_valu / step_ms, 3) if step_valu is not None else None,
+                    "step_valu_issue_ms": round(step_valu, 3) if step_valu is not None else None,
                     "traffic": traffic, "traffic_source": traffic_note,
-                    "limiter": ("vector-ALU issue: %.0f %% of the kernel's duration %s (SQ_INSTS_VALU x 4 cycles, %s)" % (
-                        100 * vfrac, "alone on the GPU" if alone_ms else "in place", os.path.basename(SQ_PROFILE)))
-                    if vfrac is not None else
-                               "not HBM (see DESIGN.md §4: every stage but gray is issue- or latency-bound)",
+                    "limiter": limiter,
                     "launches_per_step": per_step[dom], "frames_per_launch": fpl, "avg_ms": round(avg[dom], 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "timing": "HIP events on the launching stream around every stage launch of %d of the %d timed steps "
                               "(%d launches of the dominant stage); chunks of a step run concurrently on two streams, so "
-                              "an in-place duration includes the sibling chunk's share of the GPU; the resize entry "
-                              "spans its per-level kernels" % (steps_cov, a.steps, cnt[dom]),
+                              "an in-place duration includes the sibling chunk's share of the GPU (`frac` is in place, "
+                              "`frac_alone` from the serialized pass); the resize entry spans its per-level kernels" % (
+                                  steps_cov, a.steps, cnt[dom]),
                     "stages_ms_per_launch": {k: round(x, 4) for k, x in avg.items()},
                     "stages_ms_per_step": {k: round(x, 4) for k, x in acc.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0 and k in sb}}
+        st_prof, fps_prof, _ = pmc_profile()
+        if st_prof is not None:
+            roofline["traffic_MB_per_frame"] = round(sum(
+                (2 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024 for d in st_prof.values()) / fps_prof / 1e6, 2)
+            roofline["stages_valu_issue_ms"] = {k: round(valu_issue_ms(k, B), 3) for k in acc if k in st_prof}
         if "stages_ms_serialized" in extras:
             roofline["stages_ms_serialized"] = extras.pop("stages_ms_serialized")
         if "match_knn2" in acc:
@@ -631,6 +684,141 @@ def main():
                            "copy stream, overlapped with extract + match + back-projection of the previous batch; keypoints, "
                            "descriptors, matches and 3-D points (capacity-strided arrays) copied back to pinned host memory; "
                            "the headline `value` is the HBM-resident rate" % (n_pb, PB)}
+
+            if world == 1 and rank == 0 and not a.no_legs and not cv and not a.bow and not a.pnp:
+                # ---- driver-visible legs of the other single-GPU configurations of BASELINE.json (bounded: ~10 steps each)
+                def leg(tag, lctx, lstep, LB, n_steps, kp_per_step, cand_per_step, voc_L, what):
+                    """time n_steps steps (both matchers), stage events in place, and every stage alone"""
+                    def run(n, profile):
+                        if profile:
+                            lctx.set_profiling(2)
+                        t0 = time.perf_counter()
+                        for i in range(n):
+                            lstep(i)
+                        lctx.sync()
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                        tm = lctx.stage_times(cap=8192) if profile else None
+                        if profile:
+                            lctx.set_profiling(0)
+                        return dt, tm
+                    for i in range(2):
+                        lstep(i)
+                    lctx.sync()
+                    dt, tm = run(n_steps, True)
+                    tot = {}
+                    for name, ms in tm:
+                        tot[name] = tot.get(name, 0.0) + ms / n_steps
+                    lctx.set_matcher(pkg.MATCHER_POPCOUNT)
+                    lstep(0)
+                    lctx.sync()
+                    dt_pop, _ = run(n_steps, False)
+                    lctx.set_matcher(pkg.MATCHER_AUTO)
+                    lctx.set_profiling(1)
+                    alone = {}
+                    for i in range(3):
+                        lstep(i)
+                        for name, ms in lctx.stage_times():
+                            alone[name] = alone.get(name, 0.0) + ms / 3
+                    lctx.set_profiling(0)
+                    lctx.sync()
+                    lsb = stage_bytes(lctx, LB, kp_per_step, cand_per_step, 10, voc_L)
+                    # (the dominant stage by its duration ALONE: an in-place interval on one of the two chunk streams also
+                    # contains the time its launch waited for the other stream's kernels)
+                    ldom = max((k for k in alone if k in lsb), key=alone.get)
+                    pairs = LB * (kp_per_step / LB) ** 2
+                    out = {"workload": what, "value": kp_per_step * n_steps / dt, "unit": "keypoints/s",
+                           "ms_per_step": dt / n_steps * 1e3, "frames_per_step": LB, "steps": n_steps,
+                           "keypoints_per_frame": round(kp_per_step / LB, 1),
+                           "value_popcount_matcher": kp_per_step * n_steps / dt_pop,
+                           "ms_per_step_popcount_matcher": dt_pop / n_steps * 1e3,
+                           "dominant_stage": ldom, "dominant_kernel": STAGE_KERNEL.get(ldom, ldom),
+                           "dominant_ms_per_step_in_place": round(tot.get(ldom, 0.0), 4),
+                           "dominant_ms_per_step_alone": round(alone.get(ldom, 0.0), 4),
+                           # algorithmic bytes of the dominant stage over its duration alone on the GPU, against the HBM peak
+                           "dominant_hbm_frac_alone": round(lsb[ldom] / (alone[ldom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                           if alone.get(ldom) else None,
+                           "stages_ms_per_step_alone": {k: round(x, 4) for k, x in alone.items()}}
+                    if alone.get("match_knn2"):
+                        out["match_pairs_per_step"] = int(pairs)
+                        out["match_mfma_frac_alone"] = round(pairs * 512 / (alone["match_knn2"] * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)
+                    return out
+
+                # cfg3: the same stream + DBoW3 loop scoring against a 1e6-word vocabulary every frame (k = 10, L = voc_levels)
+                voc = synth.make_vocabulary(10, a.voc_levels, seed=77)
+                ctx.bow_load(voc)
+                ctx.bow_db_reserve(16 * B)  # the leg adds 15 batches of entries: no storage doubling inside the timed steps
+                extras["cfg3"] = leg("cfg3", ctx, lambda i: step(i, bow=True), B, 10, counts_per_batch[0], cand_per_batch[0],
+                                     a.voc_levels,
+                                     "cfg3: the cfg2 step + DBoW3 transform (k=10, L=%d: %d words), tf-idf + L1 vectors, scores vs the "
+                                     "last 64 frames, inverted-file adds" % (a.voc_levels, 10 ** a.voc_levels))
+                del voc
+                # cfg5: 1920x1080, 3 levels, ~10 k keypoints per frame, k = 2 matcher with ratio test (64 M+ distances per frame)
+                W5, H5, B5 = 1920, 1080, 64
+                f5 = synth.make_stream(B5, W5, H5, seed=4321)
+                d5 = torch.from_numpy(f5).cuda()
+                dd5 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W5, H5, seed=4321)[0]] * B5)).view(np.int16)).cuda()
+                area5 = -(-W5 * H5 // (640 * 480))
+                ks5 = area5 * max(1, 1000 // 370)
+                ts5 = torch.cuda.Stream()
+                ctx5 = pkg.Context(width=W5, height=H5, max_batch=B5, n_levels=3, min_node_area=370,
+                                   max_keypoints=min(32736, 4096 * ks5), max_candidates=16384 * area5, device=dev,
+                                   stream=ts5.cuda_stream)
+
+                def step5(i):
+                    ctx5.detect_batch_dev(d5.data_ptr(), B5)
+                    ctx5.match_batch_dev(0.7, True)
+                    ctx5.backproject_batch_dev(dd5.data_ptr())
+                step5(0)
+                ctx5.sync()
+                kp5 = int(pkg.read_device(ctx5, ctx5.batch_view().count, (B5,), np.int32).sum())
+                cand5 = int(ctx5.debug_counts(pkg.DBG_CANDIDATES, B5).sum())
+                extras["cfg5"] = leg("cfg5", ctx5, step5, B5, 10, kp5, cand5, a.voc_levels,
+                                     "cfg5: synthetic 1920x1080 RGB-D stream (%d distinct frames), 3-level pyramid, min-area 370, "
+                                     "extract + knn-2 ratio-test matcher vs previous frame + back-projection" % B5)
+                ctx5.close()
+                del d5, dd5, f5
+
+                # ---- what the reference's caller sees: ONE frame per call through the synchronous C-ABI entry points
+                # (rgbd_feature_frontend.cpp:187 detect, :237 match): host frame in, host arrays out
+                import ctypes as C
+                c1 = pkg.Context(width=a.width, height=a.height, max_batch=1, n_levels=a.levels, min_node_area=a.min_area, device=dev)
+                L = c1.L
+                K1 = c1.params.max_keypoints
+                xy = np.empty((K1, 2), np.float32)
+                de = np.empty((2, K1, 32), np.uint8)
+                oc = np.empty(K1, np.int32)
+                an = np.empty(K1, np.float32)
+                rs = np.empty(K1, np.float32)
+                fi = np.empty(K1, np.int32)
+                ti = np.empty(K1, np.int32)
+                n = C.c_int(0)
+                m = C.c_int(0)
+                pp = lambda x: x.ctypes.data_as(C.c_void_p)
+                t_det, t_mat, counts = [], [], [0, 0]
+                for i in range(220):
+                    fr = frames[i % 16]
+                    t0 = time.perf_counter()
+                    rc = L.mslam_hip_detect(c1._h, pp(fr), a.width, a.height, K1, pp(xy), pp(de[i & 1]), pp(oc), pp(an), pp(rs), C.byref(n))
+                    t1 = time.perf_counter()
+                    counts[i & 1] = n.value
+                    if rc == 0 and i > 0:
+                        rc = L.mslam_hip_match(c1._h, pp(de[i & 1]), counts[i & 1], pp(de[(i & 1) ^ 1]), counts[(i & 1) ^ 1],
+                                               C.c_double(0.7), pp(fi), pp(ti), C.byref(m))
+                    t2 = time.perf_counter()
+                    if rc != 0:
+                        raise RuntimeError("single-frame call failed: %d" % rc)
+                    if i >= 20:
+                        t_det.append(t1 - t0)
+                        t_mat.append(t2 - t1)
+                c1.close()
+                extras["latency_us"] = {
+                    "detect": round(float(np.median(t_det)) * 1e6, 1), "match": round(float(np.median(t_mat)) * 1e6, 1),
+                    "detect_p95": round(float(np.percentile(t_det, 95)) * 1e6, 1),
+                    "match_p95": round(float(np.percentile(t_mat, 95)) * 1e6, 1),
+                    "what": "median over 200 synchronous single-frame calls through the C ABI (mslam_hip_detect / mslam_hip_match: "
+                            "host frame in, host keypoints / descriptors / matches out, %d keypoints per frame), what "
+                            "IFeatureDetector::detect / IFeatureMatcher::match of the plugin cost per call" % counts[0]}
     except Exception as e:  # noqa: BLE001 - any failure of an extra leg must not cost the headline
         extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
 

@@ -27,6 +27,9 @@ def test_gpus_2_spawns_two_ranks():
     assert j["n_gpus"] == 2 and j["dist"]["world_size"] == 2 and j["dist"]["launched_by"] == "bench.py"
     assert j["steps"] == 3 and j["warmup"] == 1
     assert j["t_max"] == 2.0 and j["units"] == 200.0          # MAX over ranks of (1 + rank), SUM of 100 per rank
+    # the loop-candidate exchange ran over the process group: ONE collective per batch, as the first real RCCL run must show
+    assert j["exchange"]["world_size"] == 2 and j["exchange"]["collectives_per_batch"] == 1.0
+    assert j["exchange"]["bytes_per_rank_per_batch"] == 4 * 8 * (2 * 2048 + 1)
 
 
 def test_single_rank_needs_no_launcher():

@@ -5,7 +5,7 @@ TAG=$1; shift
 mkdir -p gpurun_out/$TAG
 i=0
 for cfg in "$@"; do
-  env $cfg timeout -k 10 200 python bench.py --no-cpu-baseline --steps 30 ${BENCH_ARGS:-} > gpurun_out/$TAG/ab_$i.json 2> gpurun_out/$TAG/ab_$i.err || { echo "FAILED: $cfg"; tail -3 gpurun_out/$TAG/ab_$i.err; exit 1; }
+  env $cfg timeout -k 10 200 python bench.py --no-cpu-baseline --no-legs --steps 30 ${BENCH_ARGS:-} > gpurun_out/$TAG/ab_$i.json 2> gpurun_out/$TAG/ab_$i.err || { echo "FAILED: $cfg"; tail -3 gpurun_out/$TAG/ab_$i.err; exit 1; }
   python - "gpurun_out/$TAG/ab_$i.json" "$cfg" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -8,7 +8,7 @@ timeout -k 10 600 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1
 rc=$?
 tail -5 "$OUT/pytest.log"
 if [ $rc -ne 0 ]; then exit $rc; fi
-timeout -k 10 300 python bench.py --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-legs ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
 python - "$OUT/bench.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
