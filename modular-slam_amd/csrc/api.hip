@@ -380,7 +380,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
     void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_rs_qt, c->d_ratio_thr, c->d_orient_w, c->d_stage,  c->d_pyr,
                     c->d_blur,    c->d_cv_ofs, c->d_cv_coef, c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
-                    c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_to, c->d_hm_out,
+                    c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_out,
                     c->d_xyz, c->d_valid, c->d_pnp_obj, c->d_pnp_img, c->d_pnp_n, c->d_pnp_counts, c->d_pnp_hyp, c->d_pnp_out,
                     c->d_pnp_mask, c->d_blur_waves, c->d_pnp1_obj, c->d_pnp1_img, c->d_pnp1_hyp, c->d_pnp1_out,
                     c->d_pnp1_counts, c->d_pnp1_mask};
@@ -389,6 +389,8 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
             (void)hipFree(b);
     if(c->h_out)
         (void)hipHostFree(c->h_out);
+    if(c->h_hm)
+        (void)hipHostFree(c->h_hm);
     for(auto& e : c->detect_graph)
         if(e)
             (void)hipGraphExecDestroy(e);
@@ -652,7 +654,8 @@ static int create_impl(mslam_hip_ctx* c)
 
     const size_t B = (size_t)p.max_batch, L = (size_t)p.n_levels, cap = (size_t)p.max_candidates;
     const size_t K = (size_t)p.max_keypoints;
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out), 16 + K * 52, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_out), 16 + K * 52, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_out), c->h_out, 0));
     HIPCHK(c, dmalloc(c->d_flags, 1));
     HIPCHK(c, hipMemset(c->d_flags, 0, 4));
     if(has_detector)
@@ -667,6 +670,8 @@ static int create_impl(mslam_hip_ctx* c)
             const char* e = getenv("MSLAM_HIP_FUSED_LEVELS");
             const int want = e ? atoi(e) : kMaxLevels;
             const char* k = getenv("MSLAM_HIP_LEVEL_K6");
+            const char* ks = getenv("MSLAM_HIP_LEVEL_K6_SMALL");
+            c->level_k6_small = ks ? std::max(1, atoi(ks)) : 1;
             c->level_k6 = k ? std::max(1, atoi(k)) : 9; // 9 -> 56-row blocks: the halo re-reads cost 11 % instead of 19 % (32 rows); the step time is the same
             const bool fits = (p.width & 3) == 0 && (double)B * p.width * p.height * 3 < 4294967296.0 &&
                               (double)B * g.slab < 4294967296.0 && (size_t)B * (p.width / 4) < (1u << 22) && p.height >= 8;
@@ -792,9 +797,53 @@ int mslam_hip_sync(mslam_hip_ctx* c)
     return check_flags(c);
 }
 
+// The single-frame call's results go back to the host in ONE step: this kernel writes the count, the status flags and
+// exactly `count` records of every output array into the page-locked, device-mapped staging block (h_out) — no copy
+// nodes in the graph (seven capacity-sized device-to-host copies cost 37 us of the 185 us call), nothing beyond the
+// keypoints that exist crosses PCIe.
+__global__ __launch_bounds__(256) void k_pack_results(const float* __restrict__ xy, const uint8_t* __restrict__ desc,
+                                                      const int32_t* __restrict__ octave, const float* __restrict__ angle,
+                                                      const float* __restrict__ response, const int32_t* __restrict__ count,
+                                                      const uint32_t* __restrict__ flags, uint8_t* __restrict__ h, int K)
+{
+    const int n = min(max(*count, 0), K);
+    const int tid = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+    if(tid == 0)
+    {
+        reinterpret_cast<int32_t*>(h)[0] = *count;
+        reinterpret_cast<uint32_t*>(h)[1] = *flags;
+    }
+    uint2* h_xy = reinterpret_cast<uint2*>(h + 16);
+    uint2* h_desc = reinterpret_cast<uint2*>(h + 16 + (size_t)K * 8); // (8-byte aligned for every K; 16-byte only for even K)
+    uint32_t* h_oct = reinterpret_cast<uint32_t*>(h + 16 + (size_t)K * 40);
+    uint32_t* h_ang = h_oct + K;
+    uint32_t* h_resp = h_ang + K;
+    for(int i = tid; i < 4 * n; i += nt)
+        h_desc[i] = reinterpret_cast<const uint2*>(desc)[i];
+    for(int i = tid; i < n; i += nt)
+    {
+        h_xy[i] = reinterpret_cast<const uint2*>(xy)[i];
+        h_oct[i] = reinterpret_cast<const uint32_t*>(octave)[i];
+        h_ang[i] = reinterpret_cast<const uint32_t*>(angle)[i];
+        h_resp[i] = reinterpret_cast<const uint32_t*>(response)[i];
+    }
+}
+
+// slot 0 of the next output set = the last frame of the previous batch (its descriptors are the matcher's train side)
+__global__ __launch_bounds__(256) void k_carry_prev(uint4* __restrict__ dst, const uint4* __restrict__ src, int32_t* __restrict__ dst_count,
+                                                    const int32_t* __restrict__ src_count, int K)
+{
+    const int n = min(max(*src_count, 0), K);
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    if(tid == 0)
+        *dst_count = *src_count;
+    for(int i = tid; i < 2 * n; i += gridDim.x * 256)
+        dst[i] = src[i];
+}
+
 // one level l > 0 produced and blurred in one pass (k_level.hip)
 static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, const uint32_t* ycoef, int exact, int f0, int nf,
-                                hipStream_t cs)
+                                int k6, hipStream_t cs)
 {
     const Geometry& g = c->geom;
     const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
@@ -810,7 +859,7 @@ static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, co
     ra.frame0 = f0, ra.n_frames = nf;
     ra.quads = (dl.w + 3) / 4;
     ra.inv_quads = 1.0f / (float)ra.quads;
-    ra.k6 = std::max(1, std::min(std::min(c->level_k6, 9), (dl.h - 2) / 6));
+    ra.k6 = std::max(1, std::min(std::min(k6, 9), (dl.h - 2) / 6));
     ra.need_mask = c->rs_need[l];
     ra.exact = exact;
     ra.dump_off = g.slab - 256;
@@ -824,6 +873,9 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
     const Geometry& g = c->geom;
     const size_t K = (size_t)c->p.max_keypoints;
     hipStream_t s = c->stream;
+    // rows per block of the level kernels (6 k6 + 2): long blocks for throughput (fewer halo rows), short ones for a
+    // handful of frames, where a launch is a few waves and its duration is the length of one wave's walk
+    const int k6_batch = n_frames >= 8 ? c->level_k6 : c->level_k6_small;
     // Frames are independent until the matcher, so the batch is cut into chunks that run the same
     // kernel sequence on separate HIP streams: the latency-bound kernels of one chunk (quadtree, the
     // tails of every launch) overlap the throughput-bound kernels of the other.  With profiling on,
@@ -852,7 +904,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 ga.n_frames = nf, ga.frame0 = f0;
                 ga.quads = g.W / 4;
                 ga.inv_quads = 1.0f / (float)ga.quads;
-                ga.k6 = std::max(1, std::min(c->level_k6, (g.H - 2) / 6));
+                ga.k6 = std::max(1, std::min(k6_batch, (g.H - 2) / 6));
                 ga.bk = make_blur_k();
                 launch_gray_blur(ga, cs);
             }
@@ -870,7 +922,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                     const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
                     if(l < c->fused_levels)
                     {
-                        enqueue_resize_blur(c, l, c->d_cv_ofs + c->cv_y[l], c->d_cv_coef + c->cv_y[l], 1, f0, nf, cs);
+                        enqueue_resize_blur(c, l, c->d_cv_ofs + c->cv_y[l], c->d_cv_coef + c->cv_y[l], 1, f0, nf, k6_batch, cs);
                         continue;
                     }
                     if(c->rs_q[l] != SIZE_MAX)
@@ -936,7 +988,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             {
                 if(l < c->fused_levels)
                 {
-                    enqueue_resize_blur(c, l, c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], 0, f0, nf, cs);
+                    enqueue_resize_blur(c, l, c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], 0, f0, nf, k6_batch, cs);
                     continue;
                 }
                 if(c->rs_q[l] != SIZE_MAX)
@@ -1057,8 +1109,11 @@ static int detect_prologue(mslam_hip_ctx* c)
         }
         // carry the last frame of the previous batch into slot 0 (predecessor of the new frame 0)
         const size_t last = (size_t)c->n_last;
-        HIPCHK(c, hipMemcpyAsync(c->out[nxt].desc, c->out[prev].desc + last * K * 32, K * 32, hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->out[nxt].count, c->out[prev].count + last, 4, hipMemcpyDeviceToDevice, s));
+        // (one small kernel: the count and exactly that many descriptors, instead of two copy launches of the capacity)
+        hipLaunchKernelGGL(k_carry_prev, dim3(16), dim3(256), 0, s, reinterpret_cast<uint4*>(c->out[nxt].desc),
+                           reinterpret_cast<const uint4*>(c->out[prev].desc + last * K * 32), c->out[nxt].count,
+                           c->out[prev].count + last, (int)K);
+        HIPCHK(c, hipGetLastError());
         c->have_prev = true;
         select_set(c, nxt);
     }
@@ -1124,17 +1179,10 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     uint8_t* h_oct = h_desc + K * 32;
     uint8_t* h_ang = h_oct + K * 4;
     uint8_t* h_resp = h_ang + K * 4;
-    auto enqueue_results = [&](size_t cap) -> int {
-        HIPCHK(c, hipMemcpyAsync(h, c->d_count + 1, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(h + 4, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
-        if(cap > 0)
-        {
-            HIPCHK(c, hipMemcpyAsync(h_xy, c->d_xy + K * 2, cap * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(h_desc, c->d_desc + K * 32, cap * 32, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(h_oct, c->d_octave + K, cap * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(h_ang, c->d_angle + K, cap * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(h_resp, c->d_response + K, cap * 4, hipMemcpyDeviceToHost, c->stream));
-        }
+    auto enqueue_results = [&]() -> int {
+        hipLaunchKernelGGL(k_pack_results, dim3(32), dim3(256), 0, c->stream, c->d_xy + K * 2, c->d_desc + K * 32, c->d_octave + K,
+                           c->d_angle + K, c->d_response + K, c->d_count + 1, c->d_flags, c->d_h_out, (int)K);
+        HIPCHK(c, hipGetLastError());
         return MSLAM_HIP_OK;
     };
     HIPCHK(c, hipStreamSynchronize(c->stream_m));
@@ -1153,7 +1201,7 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
             HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
             rc = enqueue_detect(c, c->d_stage, 1);
             if(!rc)
-                rc = enqueue_results(K);
+                rc = enqueue_results();
             const hipError_t e = hipStreamEndCapture(c->stream, &graph);
             if(rc)
                 return rc;
@@ -1168,7 +1216,7 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
         rc = enqueue_detect(c, c->d_stage, 1);
         if(rc)
             return rc;
-        rc = enqueue_results(std::min<size_t>(K, (size_t)max_out));
+        rc = enqueue_results();
         if(rc)
             return rc;
     }
@@ -1289,31 +1337,39 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
 
 static int host_match_prepare(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to)
 {
-    if(n_from > c->hm_from_cap)
+    // device descriptors: ONE buffer [train rows | query rows], so that one copy fills both
+    if(n_from > c->hm_from_cap || n_to > c->hm_to_cap)
     {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int from_cap = std::max(n_from, std::max(c->hm_from_cap, 2048)), to_cap = std::max(n_to, std::max(c->hm_to_cap, 2048));
         if(c->d_hm_from)
             (void)hipFree(c->d_hm_from);
-        c->d_hm_from = nullptr;
-        c->hm_from_cap = 0;
-        HIPCHK(c, dmalloc(c->d_hm_from, (size_t)n_from * 32));
-        c->hm_from_cap = n_from;
-    }
-    if(n_to > c->hm_to_cap)
-    {
-        if(c->d_hm_to)
-            (void)hipFree(c->d_hm_to);
         if(c->d_hm_out)
             (void)hipFree(c->d_hm_out);
+        if(c->h_hm)
+            (void)hipHostFree(c->h_hm);
+        c->d_hm_from = nullptr;
         c->d_hm_to = nullptr;
         c->d_hm_out = nullptr;
-        c->hm_to_cap = 0;
-        HIPCHK(c, dmalloc(c->d_hm_to, (size_t)n_to * 32));
-        HIPCHK(c, dmalloc(c->d_hm_out, (size_t)n_to * 6 + 4));
-        c->hm_to_cap = n_to;
+        c->h_hm = nullptr;
+        c->d_h_hm = nullptr;
+        c->hm_from_cap = c->hm_to_cap = 0;
+        HIPCHK(c, dmalloc(c->d_hm_from, (size_t)(from_cap + to_cap) * 32));
+        HIPCHK(c, dmalloc(c->d_hm_out, (size_t)to_cap * 6 + 4));
+        // page-locked, device-mapped: [descriptor staging (from | to) | from_idx | to_idx | n_out] — the caller's
+        // (pageable) descriptors are copied here by the CPU and go up in ONE asynchronous copy (two blocking pageable
+        // copies cost 25 us of the 84 us call); the ratio kernel writes its compacted pairs straight into the block
+        const size_t bytes = (size_t)(from_cap + to_cap) * 32 + ((size_t)to_cap * 2 + 4) * 4;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_hm), bytes, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_hm), c->h_hm, 0));
+        c->hm_from_cap = from_cap;
+        c->hm_to_cap = to_cap;
     }
+    c->d_hm_to = c->d_hm_from + (size_t)n_from * 32; // packed right behind the train rows of THIS call
     if(n_from > 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_hm_from, from_desc, (size_t)n_from * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_hm_to, to_desc, (size_t)n_to * 32, hipMemcpyHostToDevice, c->stream));
+        std::memcpy(c->h_hm, from_desc, (size_t)n_from * 32);
+    std::memcpy(c->h_hm + (size_t)n_from * 32, to_desc, (size_t)n_to * 32);
+    HIPCHK(c, hipMemcpyAsync(c->d_hm_from, c->h_hm, (size_t)(n_from + n_to) * 32, hipMemcpyHostToDevice, c->stream));
     return MSLAM_HIP_OK;
 }
 
@@ -1410,33 +1466,18 @@ int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, cons
     r.n_to_fixed = n_to;
     r.cap = n_to;
     r.thr = c->d_ratio_thr;
-    r.from_idx = c->d_hm_out + 4 * cap;
-    r.to_idx = c->d_hm_out + 5 * cap;
-    r.n_out = c->d_hm_out + 6 * cap;
+    // the compacted pairs and their count land in the mapped host block (they are small: 8 bytes per match)
+    int32_t* res_dev = reinterpret_cast<int32_t*>(c->d_h_hm + (size_t)(c->hm_from_cap + c->hm_to_cap) * 32);
+    const int32_t* res = reinterpret_cast<const int32_t*>(c->h_hm + (size_t)(c->hm_from_cap + c->hm_to_cap) * 32);
+    r.from_idx = res_dev;
+    r.to_idx = res_dev + cap;
+    r.n_out = res_dev + 2 * cap;
     launch_ratio_compact(r, 1, c->stream);
     HIPCHK(c, hipGetLastError());
-    int32_t n = 0;
-    const size_t K = (size_t)c->p.max_keypoints, words = 2 * cap + 1; // from_idx | to_idx | n_out are contiguous
-    if(words * 4 <= 16 + K * 52)
-    {
-        // one asynchronous copy of all three into the pinned staging block, one synchronisation
-        int32_t* h = reinterpret_cast<int32_t*>(c->h_out);
-        HIPCHK(c, hipMemcpyAsync(h, r.from_idx, words * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        n = h[2 * cap];
-        std::memcpy(from_idx, h, (size_t)n * 4);
-        std::memcpy(to_idx, h + cap, (size_t)n * 4);
-    }
-    else
-    {
-        HIPCHK(c, hipMemcpyAsync(&n, r.n_out, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if(n > 0)
-        {
-            HIPCHK(c, hipMemcpy(from_idx, r.from_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(to_idx, r.to_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
-        }
-    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int32_t n = res[2 * cap];
+    std::memcpy(from_idx, res, (size_t)n * 4);
+    std::memcpy(to_idx, res + cap, (size_t)n * 4);
     *n_out = n;
     return MSLAM_HIP_OK;
 }

@@ -74,6 +74,7 @@ struct mslam_hip_ctx
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
     hipGraphExec_t detect_graph[2] = {nullptr, nullptr}; // mslam_hip_detect's kernel + copy sequence, per output set
     bool use_graph = true;
+    uint8_t* d_h_out = nullptr;     // the device address of h_out (page-locked, mapped)
     uint8_t* h_out = nullptr;       // pinned staging of mslam_hip_detect's results: [count, flags | xy | desc | octave | angle | response] for K keypoints
     double ratio_cached = -1.0;
 
@@ -84,7 +85,8 @@ struct mslam_hip_ctx
     mslam::BlurWave* d_blur_waves = nullptr; // k_blur2 wave descriptors of one frame
     int blur_wpf = 0;
     int fused_levels = 0;  // levels 0 .. fused_levels-1 are produced and blurred by k_level.hip; k_blur2 takes the rest
-    int level_k6 = 10;     // k_level.hip: rows per block = 6 k6 + 2
+    int level_k6 = 9;      // k_level.hip: rows per block = 6 k6 + 2
+    int level_k6_small = 1; // the same for batches of fewer than 8 frames (latency: one wave's walk is the launch's duration)
     uint32_t* d_cell_cnt = nullptr;
     uint32_t* d_cell_kp = nullptr;
     mslam::QuadArgs quad{};
@@ -114,6 +116,7 @@ struct mslam_hip_ctx
     uint8_t *d_hm_from = nullptr, *d_hm_to = nullptr;
     int32_t* d_hm_out = nullptr; // 6 arrays x cap + 1
     int hm_from_cap = 0, hm_to_cap = 0;
+    uint8_t *h_hm = nullptr, *d_h_hm = nullptr; // page-locked, mapped staging of the host-pointer matcher (host / device address)
 
     // RGB-D back-projection outputs (allocated on first use)
     double* d_xyz = nullptr;

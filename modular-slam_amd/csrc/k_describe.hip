@@ -460,7 +460,9 @@ void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_fra
     gg.frame0 = frame0;
     DescArgs aa = a;
     aa.n_frames = n_frames;
-    static const int bpf = [] { const char* e = getenv("MSLAM_DESC_BPF"); return e ? atoi(e) : kBlocksPerFrame; }();
+    static const int bpf_env = [] { const char* e = getenv("MSLAM_DESC_BPF"); return e ? atoi(e) : 0; }();
+    // a handful of frames (the synchronous single-frame call): twice the workgroups per frame, half the keypoints per wave
+    const int bpf = bpf_env ? bpf_env : n_frames < 8 ? 2 * kBlocksPerFrame : kBlocksPerFrame;
     const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)bpf;
     hipLaunchKernelGGL(k_describe, dim3(grid), dim3(256), 0, s, gg, aa, bpf);
 }

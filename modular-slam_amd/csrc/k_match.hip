@@ -394,7 +394,12 @@ int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
     const int max_train = a.from_cnt ? a.cap_from : a.n_from_fixed;
     if(max_train <= MM_MAX_TRAIN && !a.popcount_only)
     {
-        launch_fp4<4>(a, n_pairs, s);
+        // a handful of pairs (the synchronous single-frame calls): two query tiles per wave, twice as many waves —
+        // the kernel's latency is what counts there (39 -> 13 us for one 1900 x 1900 pair), not its throughput
+        if(n_pairs <= 4)
+            launch_fp4<2>(a, n_pairs, s);
+        else
+            launch_fp4<4>(a, n_pairs, s);
         return 1;
     }
     launch_variant<8, 1, 8>(a, n_pairs, s);
