@@ -625,19 +625,50 @@ __global__ __launch_bounds__(64) void k_bow_cross_score(const uint32_t* __restri
 // ---- inverted file (DBoW3 Database::add / queryL1; sources not in the reference tree, published algorithm) -------------
 // add: every (word, value) of the new entries is appended to the log and pushed on its word's list.  Several entries
 // added by one launch may share words: atomicExch keeps every list intact whatever the order.
-__global__ void k_ix_alloc(const int32_t* __restrict__ bn, int n_entries, uint32_t* __restrict__ size,
-                           uint32_t* __restrict__ starts /*[n_entries]*/, uint32_t cap_postings, uint32_t* __restrict__ flags)
+// (one 1024-thread workgroup: exclusive prefix sum of the entries' word counts, chunk by chunk; a single thread walking
+// 1000 counts took 56 us of the cfg3 step)
+__global__ __launch_bounds__(1024) void k_ix_alloc(const int32_t* __restrict__ bn, int n_entries, uint32_t* __restrict__ size,
+                                                   uint32_t* __restrict__ starts /*[n_entries]*/, uint32_t cap_postings,
+                                                   uint32_t* __restrict__ flags)
 {
-    uint32_t s = *size;
-    for(int t = 0; t < n_entries; ++t)
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if(tid == 0)
+        run = *size;
+    __syncthreads();
+    for(int base = 0; base < n_entries; base += 1024)
     {
-        starts[t] = s;
-        s += (uint32_t)bn[t];
+        const int t = base + tid;
+        const uint32_t v = t < n_entries ? (uint32_t)bn[t] : 0u;
+        uint32_t inc = v; // inclusive scan inside the wave
+#pragma unroll
+        for(int o = 1; o < 64; o <<= 1)
+        {
+            const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+            if(lane >= o)
+                inc += u;
+        }
+        if(lane == 63)
+            wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t before = run;
+        for(int w = 0; w < wave; ++w)
+            before += wave_tot[w];
+        if(t < n_entries)
+            starts[t] = before + inc - v;
+        __syncthreads();
+        if(tid == 1023)
+            run = before + inc;
+        __syncthreads();
     }
-    if(s > cap_postings)
-        atomicOr(flags, kFlagDbFull); // nothing is appended by k_ix_append in that case
-    else
-        *size = s;
+    if(tid == 0)
+    {
+        if(run > cap_postings)
+            atomicOr(flags, kFlagDbFull); // nothing is appended by k_ix_append in that case
+        else
+            *size = run;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ix_append(const uint32_t* __restrict__ bwords, const double* __restrict__ bvalues,
@@ -1246,7 +1277,7 @@ static int ix_add(mslam_hip_ctx* c, int slot0, int n)
         if(rc)
             return rc;
     }
-    hipLaunchKernelGGL(k_ix_alloc, dim3(1), dim3(1), 0, c->stream, b->d_bn + slot0, n, b->ix_size, b->ix_ofs,
+    hipLaunchKernelGGL(k_ix_alloc, dim3(1), dim3(1024), 0, c->stream, b->d_bn + slot0, n, b->ix_size, b->ix_ofs,
                        (uint32_t)b->ix_cap_postings, c->d_flags); // ix_ofs doubles as the per-entry start scratch (n <= B + 1 <= capacity)
     hipLaunchKernelGGL(k_ix_append, dim3(n), dim3(256), 0, c->stream, b->d_bwords + (size_t)slot0 * b->cap,
                        b->d_bvalues + (size_t)slot0 * b->cap, b->d_bn + slot0, b->cap, b->next_id, b->ix_ofs, b->ix_size,

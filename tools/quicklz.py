@@ -214,3 +214,19 @@ def compress_vocabulary(blob, level=1):
     assert sig == 88877711233 and comp == 0
     n, packed = compress_stream(blob[13:], level)
     return struct.pack("<QBII", sig, 1, n_nodes, n) + packed
+
+
+def decompress_vocabulary(blob):
+    """the inverse of compress_vocabulary: a DBoW3 vocabulary stream saved with compressed = true -> the plain stream
+    (returned unchanged when it is not compressed)"""
+    sig, comp, n_nodes = struct.unpack_from("<QBI", blob, 0)
+    assert sig == 88877711233
+    if comp == 0:
+        return bytes(blob)
+    n, = struct.unpack_from("<I", blob, 13)
+    pos, out = 17, bytearray()
+    for _ in range(n):
+        data, used = decompress_packet(bytes(blob[pos:]))
+        out += data
+        pos += used
+    return struct.pack("<QBI", sig, 0, n_nodes) + bytes(out)
