@@ -860,6 +860,13 @@ static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, co
     ra.quads = (dl.w + 3) / 4;
     ra.inv_quads = 1.0f / (float)ra.quads;
     ra.k6 = std::max(1, std::min(std::min(k6, 9), (dl.h - 2) / 6));
+    // small levels: a launch of long row blocks is a single wave per SIMD or less and runs as long as ONE wave's walk.
+    // Shorten the blocks (more halo rows, more waves) until the launch has about two waves per SIMD.
+    {
+        const long waves_x = ((long)nf * ra.quads + 61) / 62;
+        while(ra.k6 > 2 && waves_x * ((dl.h + 6 * ra.k6 + 1) / (6 * ra.k6 + 2)) < 2048)
+            --ra.k6;
+    }
     ra.need_mask = c->rs_need[l];
     ra.exact = exact;
     ra.dump_off = g.slab - 256;
