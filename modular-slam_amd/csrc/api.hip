@@ -380,7 +380,7 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
     void* bufs[] = {c->d_cells,   c->d_rs_ofs, c->d_rs_coef, c->d_rs_qt, c->d_ratio_thr, c->d_orient_w, c->d_stage,  c->d_pyr,
                     c->d_blur,    c->d_cv_ofs, c->d_cv_coef, c->d_cell_cnt, c->d_cell_kp, c->quad.cand, c->quad.cand_cnt, c->quad.sel,
                     c->quad.sel_cnt, c->quad.kp_node, c->quad.nodes_a, c->quad.nodes_b, c->quad.ncnt_a, c->quad.ncnt_b,
-                    c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_out,
+                    c->quad.child_cnt, c->quad.ninfo, c->quad.best, c->d_flags, c->d_hm_from, c->d_hm_out, c->d_hm_partial,
                     c->d_xyz, c->d_valid, c->d_pnp_obj, c->d_pnp_img, c->d_pnp_n, c->d_pnp_counts, c->d_pnp_hyp, c->d_pnp_out,
                     c->d_pnp_mask, c->d_blur_waves, c->d_pnp1_obj, c->d_pnp1_img, c->d_pnp1_hyp, c->d_pnp1_out,
                     c->d_pnp1_counts, c->d_pnp1_mask};
@@ -1342,6 +1342,7 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
     return MSLAM_HIP_OK;
 }
 
+constexpr int kHostMatchSlices = 8;
 static int host_match_prepare(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to)
 {
     // device descriptors: ONE buffer [train rows | query rows], so that one copy fills both
@@ -1363,6 +1364,10 @@ static int host_match_prepare(mslam_hip_ctx* c, const uint8_t* from_desc, int n_
         c->hm_from_cap = c->hm_to_cap = 0;
         HIPCHK(c, dmalloc(c->d_hm_from, (size_t)(from_cap + to_cap) * 32));
         HIPCHK(c, dmalloc(c->d_hm_out, (size_t)to_cap * 6 + 4));
+        if(c->d_hm_partial)
+            (void)hipFree(c->d_hm_partial);
+        c->d_hm_partial = nullptr;
+        HIPCHK(c, dmalloc(c->d_hm_partial, (size_t)kHostMatchSlices * 2 * to_cap));
         // page-locked, device-mapped: [descriptor staging (from | to) | from_idx | to_idx | n_out] — the caller's
         // (pageable) descriptors are copied here by the CPU and go up in ONE asynchronous copy (two blocking pageable
         // copies cost 25 us of the 84 us call); the ratio kernel writes its compacted pairs straight into the block
@@ -1394,6 +1399,10 @@ static void host_match_args(mslam_hip_ctx* c, int n_from, int n_to, MatchArgs& m
     m.dist0 = c->d_hm_out + 2 * cap;
     m.dist1 = c->d_hm_out + 3 * cap;
     m.popcount_only = c->matcher_kind == MSLAM_HIP_MATCHER_POPCOUNT;
+    // one pair: the call's latency is the kernel's latency, so the train tiles are scanned by several workgroups side by side
+    // (about 8 tiles each) and merged (k_match.hip)
+    m.partial = c->d_hm_partial;
+    m.n_slices = std::max(1, std::min(kHostMatchSlices, (n_from + 255) / 256));
 }
 
 int mslam_hip_join_matcher(mslam_hip_ctx* c)

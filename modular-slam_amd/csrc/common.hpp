@@ -244,6 +244,10 @@ struct MatchArgs
     int32_t* dist1;
     int cap_from = 0;                 // upper bound of from_cnt[] (per-pair capacity of the train side)
     int popcount_only = 0;            // 1: the xor/popcount kernel whatever the train size (mslam_hip_set_matcher)
+    // matrix-core kernel only, a handful of pairs: the train set is cut into n_slices, scanned by separate workgroups, and
+    // merged by k_match_merge.  partial: [n_pairs][n_slices][2][cap] top-2 keys; n_slices <= 1 or partial == nullptr: off
+    uint32_t* partial = nullptr;
+    int n_slices = 0;
     int n_pairs = 0, wg_per_pair = 0; // filled in by the launcher
 };
 int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s); // returns the kernel taken: 1 = matrix cores, 2 = xor/popcount

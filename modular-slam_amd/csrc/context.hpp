@@ -116,6 +116,7 @@ struct mslam_hip_ctx
     uint8_t *d_hm_from = nullptr, *d_hm_to = nullptr;
     int32_t* d_hm_out = nullptr; // 6 arrays x cap + 1
     int hm_from_cap = 0, hm_to_cap = 0;
+    uint32_t* d_hm_partial = nullptr; // per-slice top-2 keys of the sliced single-pair matcher
     uint8_t *h_hm = nullptr, *d_h_hm = nullptr; // page-locked, mapped staging of the host-pointer matcher (host / device address)
 
     // RGB-D back-projection outputs (allocated on first use)

@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         reinterpret_cast<const uint32_t*>(a.from_desc + (long long)pair * a.from_stride);
     const uint8_t* to = a.to_desc + (long long)pair * a.to_stride;
     const int n_tiles = (n_from + 31) >> 5;
+    // a.n_slices > 1 (a handful of pairs: the synchronous single-frame calls): blockIdx.y scans only its share of the train
+    // tiles and leaves its top-2 KEYS in a.partial; k_match_merge picks the overall top-2 (the keys carry distance and train
+    // index, so they compare across slices once their age field counts from the end of the whole train set)
+    const int t_begin = a.n_slices > 1 ? (int)((long long)n_tiles * blockIdx.y / a.n_slices) : 0;
+    const int t_end = a.n_slices > 1 ? (int)((long long)n_tiles * (blockIdx.y + 1) / a.n_slices) : n_tiles;
 
     if(n_tiles == 0)
     {
@@ -306,11 +311,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for(int i = 0; i < 16; ++i)
         pend[i] = 0u; // "tile -1": keys below 2^15 never beat a real neighbour
     uint32_t d_next;
-    stage(0, fetch(0));
-    d_next = fetch(1);
+    if(t_end > t_begin) // (an empty slice keeps "no neighbour": more slices than tiles)
+    {
+    stage(t_begin & 1, fetch(t_begin));
+    d_next = fetch(t_begin + 1);
     __syncthreads();
-    const int n_full = n_tiles - 1; // the last tile (possibly partial) is peeled: its keys need masking
-    for(int t = 0; t < n_full; ++t)
+    const int n_full = t_end - 1; // the slice's last tile (the only one that can be partial) is peeled: its keys need masking
+    for(int t = t_begin; t < n_full; ++t)
     {
         const int buf = t & 1;
         stage(buf ^ 1, d_next);
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             pend[i] = keyB[i];
         __syncthreads();
     }
-    if(n_full > 0)
+    if(n_full > t_begin)
         top2(pend, best0[QT - 1], best1[QT - 1]);
     {
         v8i af[4];
@@ -351,6 +358,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             top2(keyA, best0[u], best1[u]);
         }
     }
+    } // t_end > t_begin
 
 #pragma unroll
     for(int u = 0; u < QT; ++u)
@@ -360,6 +368,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         const uint32_t m0 = max(best0[u], p0);
         const uint32_t m1 = max(min(best0[u], p0), max(best1[u], p1));
         const int q = q0 + (wave * QT + u) * 32 + r;
+        if(a.n_slices > 1)
+        {
+            if(h == 0 && q < n_to)
+            {
+                // age counted from the end of the whole train set: + 32 per tile behind this slice (exact: integers < 2^24);
+                // "no neighbour" keys stay below 2^15 (at most 1023 tiles)
+                const float behind = 32.f * (float)(n_tiles - t_end);
+                uint32_t* part = a.partial + ((size_t)pair * a.n_slices + blockIdx.y) * 2 * a.cap;
+                part[q] = __float_as_uint(__uint_as_float(m0) + behind);
+                part[a.cap + q] = __float_as_uint(__uint_as_float(m1) + behind);
+            }
+            continue;
+        }
         if(h == 0 && q < n_to)
         {
             const size_t o = (size_t)pair * a.cap + q;
@@ -374,12 +395,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 }
 
+// overall top-2 of a query from the slices' top-2 keys (k_match_knn2_fp4 with n_slices > 1), decoded like the kernel's own end
+__global__ __launch_bounds__(256) void k_match_merge(MatchArgs a)
+{
+    const int pair = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int n_from = min(a.from_cnt ? a.from_cnt[pair] : a.n_from_fixed, MM_MAX_TRAIN);
+    const int n_to = min(a.to_cnt ? a.to_cnt[pair] : a.n_to_fixed, a.cap);
+    if(q >= n_to)
+        return;
+    const int n_tiles = (n_from + 31) >> 5;
+    uint32_t b0 = 0u, b1 = 0u;
+    for(int s = 0; s < (n_tiles ? a.n_slices : 0); ++s) // (no train rows: the slices wrote nothing)
+    {
+        const uint32_t* part = a.partial + ((size_t)pair * a.n_slices + s) * 2 * a.cap;
+        const uint32_t k0 = part[q], k1 = part[a.cap + q]; // k0 >= k1
+        b1 = max(min(b0, k0), max(b1, k1));
+        b0 = max(b0, k0);
+    }
+    const size_t o = (size_t)pair * a.cap + q;
+    const int last = 32 * n_tiles - 1;
+    const uint32_t k0 = (uint32_t)__uint_as_float(b0), k1 = (uint32_t)__uint_as_float(b1); // exact integers
+    a.idx0[o] = (k0 >> 15) ? last - (int)(k0 & 32767u) : -1;
+    a.idx1[o] = (k1 >> 15) ? last - (int)(k1 & 32767u) : -1;
+    a.dist0[o] = (k0 >> 15) ? (int32_t)(257u - (k0 >> 15)) : INT_MAX;
+    a.dist1[o] = (k1 >> 15) ? (int32_t)(257u - (k1 >> 15)) : INT_MAX;
+}
+
 template <int QT>
 static void launch_fp4(MatchArgs a, int n_pairs, hipStream_t s)
 {
     a.n_pairs = n_pairs;
     a.wg_per_pair = (a.cap + 128 * QT - 1) / (128 * QT);
     const unsigned grid = (unsigned)((n_pairs + 7) / 8) * 8u * (unsigned)a.wg_per_pair;
+    if(a.n_slices > 1 && a.partial)
+    {
+        hipLaunchKernelGGL((k_match_knn2_fp4<QT>), dim3(grid, a.n_slices), dim3(256), 0, s, a);
+        // (merging inside k_ratio_compact instead of a launch of its own measured slower: 51.6 vs 49.4 us per call — that kernel
+        // is one workgroup walking the queries in order)
+        hipLaunchKernelGGL(k_match_merge, dim3((a.cap + 255) / 256, n_pairs), dim3(256), 0, s, a);
+        return;
+    }
+    a.n_slices = 1;
     hipLaunchKernelGGL((k_match_knn2_fp4<QT>), dim3(grid), dim3(256), 0, s, a);
 }
 
