@@ -1193,12 +1193,13 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
         return MSLAM_HIP_OK;
     };
     HIPCHK(c, hipStreamSynchronize(c->stream_m));
-    HIPCHK(c, hipMemcpyAsync(c->d_stage, bgr, (size_t)width * height * 3, hipMemcpyHostToDevice, c->stream));
+    // (the carry kernel of the prologue is queued first: it runs while the host stages the pageable frame for the copy)
     int rc = detect_prologue(c);
     if(rc)
         return rc;
-    // The single-frame call is launch-bound (12 small kernels + 7 copies), so its fixed sequence is captured
-    // once per output set into a HIP graph and replayed.  With stage timing on, the plain path runs.
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, bgr, (size_t)width * height * 3, hipMemcpyHostToDevice, c->stream));
+    // The single-frame call is launch-bound (11 small kernels), so its fixed sequence — kernels + the result packing
+    // kernel — is captured once per output set into a HIP graph and replayed.  With stage timing on, the plain path runs.
     if(!c->profiling && !c->inplace_timing && c->use_graph)
     {
         hipGraphExec_t& exec = c->detect_graph[c->cur];

@@ -173,7 +173,12 @@ constexpr int MM_TROW = 144;          // bytes of one expanded train row in LDS:
 constexpr int MM_MAX_TRAIN = 32736;   // 32 * 1023: the age field is 15 bits (keys stay below 2^24: exact in f32)
 constexpr float MM_KEY_UNIT = 32768.f;
 
-template <int QT>
+// SKIP (large train sets): before the 34-instruction top-2 update of a (train tile, query tile) block the wave checks whether
+// ANY of its keys beats the lane's current runner-up (8 v_max3 + a compare); if none does — the common case once a few
+// hundred rows have been seen — the update is skipped and the ageing of the bests (+32 per tile) is owed as a wave-uniform
+// scalar.  Exact: a key that does not beat the runner-up cannot enter the top-2, and equal keys do not exist (the age
+// fields differ).  Costs 10 instructions per block where it does not fire, so small train sets (cfg2) run without it.
+template <int QT, bool SKIP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_match_knn2_fp4(MatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[2][32 * MM_TROW];
@@ -276,9 +281,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         zero[i] = 0u;
     }
     uint32_t best0[QT], best1[QT];
+    float owed[QT]; // SKIP: ageing not yet added to (best0, best1): 32 per skipped block, wave-uniform
 #pragma unroll
     for(int u = 0; u < QT; ++u)
+    {
         best0[u] = best1[u] = 0u;
+        owed[u] = 0.f;
+    }
 
     auto dots = [&](const v8i (&af)[4], int u, uint32_t (&key)[16]) {
         v16f acc = cinit;
@@ -290,9 +299,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             key[i] = __float_as_uint(acc[i]);
     };
     // running top-2 of one query over the 16 train rows a lane holds of one tile
-    auto top2 = [&](const uint32_t (&key)[16], uint32_t& b0, uint32_t& b1) {
+    auto top2 = [&](const uint32_t (&key)[16], uint32_t& b0, uint32_t& b1, float& lag) {
+        if(SKIP)
+        {
+            uint32_t mx = max(max(key[0], key[1]), key[2]);
+#pragma unroll
+            for(int i = 3; i < 15; i += 2)
+                mx = max(max(mx, key[i]), key[i + 1]);
+            mx = max(mx, key[15]);
+            const float age = lag + 32.f; // what the bests have aged by the time these keys compete
+            // keys are positive floats holding integers: they order like their bit patterns
+            if(__ballot(mx > __float_as_uint(__uint_as_float(b1) + age)) == 0ull)
+            {
+                lag = age;
+                return;
+            }
+            b0 = __float_as_uint(__uint_as_float(b0) + age);
+            b1 = __float_as_uint(__uint_as_float(b1) + age);
+            lag = 0.f;
+        }
+        else
+        {
         b0 = __float_as_uint(__uint_as_float(b0) + 32.f); // everything found so far is one tile older
         b1 = __float_as_uint(__uint_as_float(b1) + 32.f);
+        }
 #pragma unroll
         for(int i = 0; i < 16; ++i)
         {
@@ -326,15 +356,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         read_frags(buf, af);
         static_assert(QT == 2 || QT == 4, "pipeline below is written for 2 or 4 query tiles per wave");
         dots(af, 0, keyA);
-        top2(pend, best0[QT - 1], best1[QT - 1]);
+        top2(pend, best0[QT - 1], best1[QT - 1], owed[QT - 1]);
         dots(af, 1, keyB);
-        top2(keyA, best0[0], best1[0]);
+        top2(keyA, best0[0], best1[0], owed[0]);
         if(QT == 4)
         {
             dots(af, 2, keyA);
-            top2(keyB, best0[1], best1[1]);
+            top2(keyB, best0[1], best1[1], owed[1]);
             dots(af, 3, keyB);
-            top2(keyA, best0[2], best1[2]);
+            top2(keyA, best0[2], best1[2], owed[2]);
         }
 #pragma unroll
         for(int i = 0; i < 16; ++i)
@@ -342,7 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         __syncthreads();
     }
     if(n_full > t_begin)
-        top2(pend, best0[QT - 1], best1[QT - 1]);
+        top2(pend, best0[QT - 1], best1[QT - 1], owed[QT - 1]);
     {
         v8i af[4];
         read_frags(n_full & 1, af);
@@ -355,11 +385,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for(int i = 0; i < 16; ++i)
                 if(base + (i & 3) + 8 * (i >> 2) + 4 * h >= n_from)
                     keyA[i] = 0u;
-            top2(keyA, best0[u], best1[u]);
+            top2(keyA, best0[u], best1[u], owed[u]);
         }
     }
     } // t_end > t_begin
 
+    if(SKIP)
+    {
+#pragma unroll
+        for(int u = 0; u < QT; ++u)
+        {
+            best0[u] = __float_as_uint(__uint_as_float(best0[u]) + owed[u]);
+            best1[u] = __float_as_uint(__uint_as_float(best1[u]) + owed[u]);
+        }
+    }
 #pragma unroll
     for(int u = 0; u < QT; ++u)
     {
@@ -422,7 +461,7 @@ __global__ __launch_bounds__(256) void k_match_merge(MatchArgs a)
     a.dist1[o] = (k1 >> 15) ? (int32_t)(257u - (k1 >> 15)) : INT_MAX;
 }
 
-template <int QT>
+template <int QT, bool SKIP = false>
 static void launch_fp4(MatchArgs a, int n_pairs, hipStream_t s)
 {
     a.n_pairs = n_pairs;
@@ -430,14 +469,14 @@ static void launch_fp4(MatchArgs a, int n_pairs, hipStream_t s)
     const unsigned grid = (unsigned)((n_pairs + 7) / 8) * 8u * (unsigned)a.wg_per_pair;
     if(a.n_slices > 1 && a.partial)
     {
-        hipLaunchKernelGGL((k_match_knn2_fp4<QT>), dim3(grid, a.n_slices), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_match_knn2_fp4<QT, SKIP>), dim3(grid, a.n_slices), dim3(256), 0, s, a);
         // (merging inside k_ratio_compact instead of a launch of its own measured slower: 51.6 vs 49.4 us per call — that kernel
         // is one workgroup walking the queries in order)
         hipLaunchKernelGGL(k_match_merge, dim3((a.cap + 255) / 256, n_pairs), dim3(256), 0, s, a);
         return;
     }
     a.n_slices = 1;
-    hipLaunchKernelGGL((k_match_knn2_fp4<QT>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_match_knn2_fp4<QT, SKIP>), dim3(grid), dim3(256), 0, s, a);
 }
 
 int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
@@ -453,8 +492,11 @@ int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
     {
         // a handful of pairs (the synchronous single-frame calls): two query tiles per wave, twice as many waves —
         // the kernel's latency is what counts there (39 -> 13 us for one 1900 x 1900 pair), not its throughput
+        static const int skip_from = [] { const char* e = getenv("MSLAM_HIP_MATCH_SKIP_FROM"); return e ? atoi(e) : 6000; }();
         if(n_pairs <= 4)
             launch_fp4<2>(a, n_pairs, s);
+        else if(max_train >= skip_from) // long scans (cfg5: 10 k train rows): most late blocks cannot change a top-2
+            launch_fp4<4, true>(a, n_pairs, s);
         else
             launch_fp4<4>(a, n_pairs, s);
         return 1;
