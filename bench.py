@@ -343,7 +343,8 @@ def main():
         if a.bow:
             # every step adds a batch of entries to the inverted file: reserve them, so that no storage doubling (a
             # reallocation + copy of the posting log) falls into the timed steps
-            ctx.bow_db_reserve((max(a.warmup, n_batches) + 3 * a.steps + 16) * B)
+            # (at most 2^31 / max_keypoints entries are addressable; beyond the reservation the storage doubles as usual)
+            ctx.bow_db_reserve(min((max(a.warmup, n_batches) + 3 * a.steps + 16) * B, (1 << 31) // ctx.params.max_keypoints - 1))
         cross = CrossStreamLoopCandidates(k_max=2048 * k_scale)
 
     def step(i, bow=a.bow):
