@@ -89,6 +89,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     __syncthreads();
 
+    // LDS byte offset of the list's fill counter (for the hand-written reservation in phase A)
+    const uint32_t n_cand_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(&n_cand);
     uint32_t total = 0;
     for(int pass = 0; pass < 2; ++pass)
     {
@@ -151,10 +153,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 if(tot != 0)
                 {
-                    uint32_t base = 0;
-                    if(lane == 0)
-                        base = atomicAdd(&n_cand, tot);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    // one lane reserves the wave's range of the list.  Written out by hand: around `if(lane == 0) atomicAdd(..)`
+                    // the compiler's atomic optimiser builds a wave reduction (mbcnt, bcnt, a multiply, two exec-mask
+                    // regions: ~8 vector instructions per step) for a value that is wave-uniform already.
+                    uint32_t base;
+                    {
+                        uint32_t got;
+                        unsigned long long save;
+                        const uint32_t add = tot; // (a vector register copy of the wave-uniform count)
+                        asm volatile("s_mov_b64 %1, exec\n\t"
+                                     "s_mov_b64 exec, 1\n\t"
+                                     "ds_add_rtn_u32 %0, %2, %3\n\t"
+                                     "s_waitcnt lgkmcnt(0)\n\t"
+                                     "s_mov_b64 exec, %1"
+                                     : "=&v"(got), "=&s"(save)
+                                     : "v"(n_cand_lds), "v"(add)
+                                     : "memory");
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                    }
                     uint32_t pos = base + inc - cnt;
                     const uint32_t yx = (uint32_t)((y << 8) | xl);
                     // slot = kept ? pos : dump as ONE v_bfi_b32 on an all-ones / all-zeros mask (v_bfe_i32), and the
