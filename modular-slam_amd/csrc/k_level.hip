@@ -27,6 +27,8 @@ namespace mslam
 {
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) BufRsrc;
 
 __device__ __forceinline__ uint32_t lv_dot2u(uint32_t pair, uint32_t taps, uint32_t acc)
 {
@@ -183,11 +185,13 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
     uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.pitch : dump_v; // blurred row of block row i = 0 (used from i = 6 on)
     const uint32_t row_bytes = (uint32_t)a.W * 3u;
 
+    // buffer loads: the wave-uniform row offset rides in the scalar offset operand, the lane's offset in the vector one —
+    // no 64-bit vector address arithmetic per load (the compiler built a v_mad_u64_u32 per row for `row pointer + lane offset`)
+    const BufRsrc bgr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.bgr), 0, -1, 0x00020000);
     auto load = [&](int i) {
         const int y = reflect_row(y0 - 3 + i, a.H);
-        const uint8_t* rowp = a.bgr + (size_t)y * row_bytes; // wave-uniform
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + src_v);
-        return Bgr3{p[0], p[1], p[2]};
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(bgr_rs, (int)src_v, (int)((uint32_t)y * row_bytes), 0);
+        return Bgr3{v.x, v.y, v.z};
     };
     BlurRing st;
 #pragma unroll
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.dpitch : dump_v;
     const uint8_t* src_lv = a.pyr + a.src_off;
 
-    auto load = [&](int sy) {
-        const uint8_t* rowp = src_lv + (size_t)sy * (uint32_t)a.spitch; // wave-uniform
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + src_v);
-        return Raw3{p[0], p[1], p[2]};
+    const BufRsrc src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, -1, 0x00020000);
+    auto load = [&](int sy) { // (buffer load: scalar row offset + vector lane offset, see k_gray_blur)
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(src_rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), 0);
+        return Raw3{v.x, v.y, v.z};
     };
     auto hinterp = [&](const Raw3& w) {
         HRow r;
