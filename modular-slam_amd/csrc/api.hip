@@ -164,7 +164,6 @@ static int build_geometry(mslam_hip_ctx* c)
     for(int l = 1; l < p.n_levels; ++l)
         scale[l] = p.scale_factor * scale[l - 1];
     unsigned offset = 0;
-    int n_strips = 0;
     c->cells.clear();
     for(int l = 0; l < p.n_levels; ++l)
     {
@@ -219,11 +218,7 @@ static int build_geometry(mslam_hip_ctx* c)
         if(lv.n_cells > 2048)
             return fail(c, MSLAM_HIP_E_INVALID, "more than 2048 FAST cells on one level");
 
-        // blur strips: one thread per 4 columns x kBlurRows rows
-        lv.bsx = (lv.w + 3) / 4;
-        lv.tile_base = n_strips;
-        lv.n_tiles = lv.bsx * ((lv.h + kBlurRows - 1) / kBlurRows);
-        n_strips += lv.n_tiles;
+        lv.bsx = (lv.w + 3) / 4; // 4-column strips per row (k_blur2)
 
         // quadtree initial grid (:1031-1052) on the bordered rectangle [19, w-19) x [19, h-19)
         const int min_x = kBorder, max_x = lv.w - kBorder, min_y = kBorder, max_y = lv.h - kBorder;
@@ -247,7 +242,6 @@ static int build_geometry(mslam_hip_ctx* c)
     }
     g.slab = offset + 256;
     g.n_cells = (int)c->cells.size();
-    g.n_tiles = n_strips;
     return MSLAM_HIP_OK;
 }
 
@@ -262,7 +256,6 @@ static int build_geometry_cv(mslam_hip_ctx* c)
     g.H = p.height;
     const double sf = (double)p.scale_factor;
     unsigned offset = 0;
-    int n_strips = 0;
     c->cells.clear();
     for(int l = 0; l < p.n_levels; ++l)
     {
@@ -282,13 +275,9 @@ static int build_geometry_cv(mslam_hip_ctx* c)
         lv.bw = lv.w - 2 * kBorder;
         lv.bh = lv.h - 2 * kBorder;
         lv.bsx = (lv.w + 3) / 4;
-        lv.tile_base = n_strips;
-        lv.n_tiles = lv.bsx * ((lv.h + kBlurRows - 1) / kBlurRows);
-        n_strips += lv.n_tiles;
     }
     g.slab = offset + 256;
     g.n_cells = 0;
-    g.n_tiles = n_strips;
     const float factor = (float)(1.0 / sf);
     float desired = (float)p.n_features * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.n_levels));
     int sum = 0;

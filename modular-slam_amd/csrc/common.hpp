@@ -23,9 +23,7 @@ struct LevelGeom
     int bw, bh;     // bordered width/height = w-38, h-38
     int cell_base;  // index of this level's first cell in the cell table
     int n_cells;    // cells kept after the skip rule (:881-905)
-    int tile_base;  // blur: index of this level's first strip thread
-    int n_tiles;    // blur: strip threads of this level = bsx * ceil(h / kBlurRows)
-    int bsx;        // blur: 4-px strips per row = ceil(w / 4)
+    int bsx;        // blur (k_blur2): 4-px strips per row = ceil(w / 4)
     // quadtree initial grid (:1031-1052)
     int nxg, nyg;
     double delta_x, delta_y;
@@ -35,7 +33,7 @@ struct Geometry
 {
     int n_levels;
     int W, H;
-    int n_cells, n_tiles;
+    int n_cells;
     int frame0;    // first frame this launch works on (blockIdx is relative to it)
     unsigned slab; // bytes per frame (all levels)
     LevelGeom lv[kMaxLevels];
