@@ -465,6 +465,9 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_note,
                     "limiter": limiter,
                     "launches_per_step": per_step[dom], "frames_per_launch": fpl, "avg_ms": round(avg[dom], 4),
+                    # a "launch" of the resize stage is one kernel per level > 0: rocprofv3's per-kernel average is avg_ms / this
+                    "kernels_per_launch": (a.levels - 1) if dom == "resize" else 1,
+                    "avg_ms_per_kernel": round(avg[dom] / ((a.levels - 1) if dom == "resize" else 1), 4),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "timing": "HIP events on the launching stream around every stage launch of %d of the %d timed steps "
                               "(%d launches of the dominant stage); chunks of a step run concurrently on two streams, so "
