@@ -24,8 +24,8 @@
 namespace mslam
 {
 
-constexpr int kTileP = 76; // tile row pitch in bytes: 19 dwords; tile dword q holds sub-image columns 4q-1 .. 4q+2,
-constexpr int kTileX = 1;  // i.e. tile byte = column + 1, so the tested columns 3+4i .. 6+4i are dword 1+i
+constexpr int kTileP = 80; // tile row pitch in bytes: five 16-byte LDS-DMA chunks from column x0 - 3 on (a 16-byte boundary),
+constexpr int kTileX = 3;  // i.e. tile byte = column + 3: the tested columns 3+4i .. 6+4i are bytes 6+4i .. 9+4i
 constexpr int kScP = 68;   // score-map row pitch
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                     uint32_t* __restrict__ cell_kp, int ini_thr, int min_thr, int n_frames)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileP];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kScP];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[(66 * kScP + 15) / 16 * 16];
     __shared__ __attribute__((aligned(4))) uint16_t cand[64 * 64 + 2];
     constexpr uint32_t kDump = 64 * 64; // write-only slot for rejected pixels
     __shared__ uint32_t bitmap[64 * 2];
@@ -60,33 +60,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int cw = c.cw, ch = c.ch;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // zero the score map (untested pixels must read 0, like FAST_t's zeroed row buffers) and the bitmap
-    for(int i = tid; i < 66 * kScP / 4; i += 256)
-        reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    // stage the sub-image by LDS-DMA: the cell's rows start at column x0 - 3 = 16 + 64 j, a 16-byte boundary of the level
+    // plane (pitch and level offset are multiples of 16), so a row is five 16-byte chunks that go from global memory
+    // straight into the tile — no registers, no vector instructions for the copy (round 2 staged through registers
+    // with a 2-byte shift to make the tested columns dword-aligned: ~45 instructions per wave; the unshifted image
+    // costs phase A three more v_alignbyte per step).  Chunk t = (row t / 5, chunk t % 5) lands at tile + 16 t.
+    {
+        const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - 3);
+        const int n_chunks = ch * 5;
+#pragma unroll
+        for(int p = 0; p < 2; ++p)
+        {
+            const int t = p * 256 + tid;
+            if(t < n_chunks)
+            {
+                const int r = (t * 13108) >> 16, j = t - r * 5; // t / 5 for t < 16384
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + (size_t)r * lv.pitch + 16 * j),
+                    (__attribute__((address_space(3))) void*)&tile[(p * 256 + wave * 64) * 16], 16, 0, 0);
+            }
+        }
+    }
+    // meanwhile: zero the score map (untested pixels must read 0, like FAST_t's zeroed row buffers) and the bitmap
+    for(int i = tid; i < (66 * kScP + 15) / 16; i += 256)
+        reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
     if(tid < 128)
         bitmap[tid] = 0;
     if(tid == 0)
         n_cand = 0;
-
-    // stage the sub-image: aligned global dwords start at column x0 - 3 (x0 = 19 + 64 j), the LDS image is
-    // shifted by two bytes (v_alignbyte) so that the tested columns are dword aligned in LDS.  One 12-byte load
-    // per lane yields two LDS dwords (LDS dword q = global bytes 4q+2 .. 4q+5): 10 lanes per 76-byte row, so a
-    // wave-load spans 6.4 rows instead of the 3.4 of a dword-per-lane copy that also fetched every dword twice —
-    // the texture path charges per row segment touched.
-    {
-        const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - 3);
-        const int n_items = ch * 10;
-        for(int i = tid; i < n_items; i += 256)
-        {
-            const int r = (i * 6554) >> 16, j = i - r * 10; // i / 10 for i < 16384
-            const uint32_t* gp = reinterpret_cast<const uint32_t*>(src + (size_t)r * lv.pitch + 8 * j);
-            const uint32_t g0 = gp[0], g1 = gp[1], g2 = gp[2];
-            uint32_t* t = reinterpret_cast<uint32_t*>(tile) + r * 19 + 2 * j;
-            t[0] = __builtin_amdgcn_alignbyte(g1, g0, 2);
-            if(j < 9) // dword 19 does not exist
-                t[1] = __builtin_amdgcn_alignbyte(g2, g1, 2);
-        }
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the wave's DMA chunks have landed
     __syncthreads();
 
     // LDS byte offset of the list's fill counter (for the hand-written reservation in phase A)
@@ -114,11 +116,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 uint32_t keep = 0;
                 if(colmask != 0 && y < ch - 3)
                 {
-                    const uint32_t* row = T + y * 19 + i4;
-                    const uint32_t L = row[0], C = row[1], R = row[2];
-                    const uint32_t U = row[1 - 3 * 19], D = row[1 + 3 * 19];
-                    const uint32_t Lf = __builtin_amdgcn_alignbyte(C, L, 1); // columns x-3 of the four pixels
-                    const uint32_t Rt = __builtin_amdgcn_alignbyte(R, C, 3); // columns x+3
+                    // the four tested pixels are bytes 6+4i .. 9+4i of the row: dwords (i+1, i+2) shifted by two bytes
+                    const uint32_t* row = T + y * 20 + i4;
+                    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];
+                    const uint32_t C = __builtin_amdgcn_alignbyte(d2, d1, 2);
+                    const uint32_t U = __builtin_amdgcn_alignbyte(row[2 - 3 * 20], row[1 - 3 * 20], 2);
+                    const uint32_t D = __builtin_amdgcn_alignbyte(row[2 + 3 * 20], row[1 + 3 * 20], 2);
+                    const uint32_t Lf = __builtin_amdgcn_alignbyte(d1, d0, 3); // columns x-3 of the four pixels
+                    const uint32_t Rt = __builtin_amdgcn_alignbyte(d3, d2, 1); // columns x+3
                     uint32_t k[2];
 #pragma unroll
                     for(int h = 0; h < 2; ++h)
