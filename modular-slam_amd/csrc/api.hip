@@ -159,6 +159,7 @@ static int build_geometry(mslam_hip_ctx* c)
     g.n_levels = p.n_levels;
     g.W = p.width;
     g.H = p.height;
+    g.blur_tiled = 0;
     float scale[kMaxLevels];
     scale[0] = 1.0f;
     for(int l = 1; l < p.n_levels; ++l)
@@ -177,9 +178,9 @@ static int build_geometry(mslam_hip_ctx* c)
                         "pyramid level " + std::to_string(l) + " is smaller than the 19-px border + one cell");
         if(lv.w > 4095 + kBorder || lv.h > 4095 + kBorder)
             return fail(c, MSLAM_HIP_E_INVALID, "frames larger than 4096 px per side are not supported");
-        lv.pitch = (lv.w + 15) & ~15;
+        lv.pitch = (lv.w + kTileW - 1) & ~(kTileW - 1); // whole tiles (common.hpp: tiled_off); kTileW is a multiple of 16
         lv.offset = (int)offset;
-        offset += ((unsigned)lv.pitch * lv.h + 255u) & ~255u;
+        offset += ((unsigned)lv.pitch * ((lv.h + kTileH - 1) & ~(kTileH - 1)) + 255u) & ~255u; // whole tile rows
         lv.bw = lv.w - 2 * kBorder;
         lv.bh = lv.h - 2 * kBorder;
 
@@ -254,6 +255,7 @@ static int build_geometry_cv(mslam_hip_ctx* c)
     g.n_levels = p.n_levels;
     g.W = p.width;
     g.H = p.height;
+    g.blur_tiled = 0;
     const double sf = (double)p.scale_factor;
     unsigned offset = 0;
     c->cells.clear();
@@ -269,9 +271,9 @@ static int build_geometry_cv(mslam_hip_ctx* c)
             return fail(c, MSLAM_HIP_E_INVALID, "pyramid level " + std::to_string(l) + " is smaller than 16 px");
         if(lv.w > 4095 || lv.h > 4095)
             return fail(c, MSLAM_HIP_E_INVALID, "frames larger than 4095 px per side are not supported");
-        lv.pitch = (lv.w + 15) & ~15;
+        lv.pitch = (lv.w + kTileW - 1) & ~(kTileW - 1); // whole tiles (common.hpp: tiled_off); kTileW is a multiple of 16
         lv.offset = (int)offset;
-        offset += ((unsigned)lv.pitch * lv.h + 255u) & ~255u;
+        offset += ((unsigned)lv.pitch * ((lv.h + kTileH - 1) & ~(kTileH - 1)) + 255u) & ~255u; // whole tile rows
         lv.bw = lv.w - 2 * kBorder;
         lv.bh = lv.h - 2 * kBorder;
         lv.bsx = (lv.w + 3) / 4;
@@ -670,6 +672,9 @@ static int create_impl(mslam_hip_ctx* c)
                   (size_t)B * ((g.lv[n_fused].w + 3) / 4) < (1u << 22))
                 ++n_fused;
             c->fused_levels = std::max(0, std::min(want, n_fused));
+            // every level from k_level.hip: the blurred slab (written there, read by k_describe only) is kept in tiles (common.hpp)
+            const char* t = getenv("MSLAM_HIP_TILED_BLUR");
+            c->geom.blur_tiled = c->fused_levels == p.n_levels && !(t && atoi(t) == 0) ? 1 : 0;
         }
         std::vector<BlurWave> bw;
         build_blur_waves(g, c->fused_levels, bw);
@@ -859,6 +864,7 @@ static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, co
     ra.need_mask = c->rs_need[l];
     ra.exact = exact;
     ra.dump_off = g.slab - 256;
+    ra.blur_tiled = g.blur_tiled;
     ra.bk = make_blur_k();
     launch_resize_blur(ra, cs);
 }
@@ -901,6 +907,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 ga.quads = g.W / 4;
                 ga.inv_quads = 1.0f / (float)ga.quads;
                 ga.k6 = std::max(1, std::min(k6_batch, (g.H - 2) / 6));
+                ga.blur_tiled = g.blur_tiled;
                 ga.bk = make_blur_k();
                 launch_gray_blur(ga, cs);
             }
@@ -1520,6 +1527,17 @@ int mslam_hip_debug_read(mslam_hip_ctx* c, int what, int frame, int level, void*
         if(dst_bytes < need)
             return fail(c, MSLAM_HIP_E_CAPACITY, "debug_read: buffer too small");
         const uint8_t* src = (what == MSLAM_HIP_DBG_PYRAMID ? c->d_pyr : c->d_blur) + (size_t)frame * c->geom.slab + lv.offset;
+        if(what == MSLAM_HIP_DBG_BLURRED && c->geom.blur_tiled)
+        {
+            // the blurred slab is stored in tiles: copy the plane's tile rows and put the rows back together here
+            std::vector<uint8_t> tmp((size_t)lv.pitch * ((lv.h + kTileH - 1) & ~(kTileH - 1)));
+            HIPCHK(c, hipMemcpy(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost));
+            uint8_t* out = static_cast<uint8_t*>(dst);
+            for(int y = 0; y < lv.h; ++y)
+                for(int x = 0; x < lv.w; ++x)
+                    out[(size_t)y * lv.w + x] = tmp[tiled_off((unsigned)lv.pitch, x, y)];
+            return MSLAM_HIP_OK;
+        }
         HIPCHK(c, hipMemcpy2D(dst, lv.w, src, lv.pitch, lv.w, lv.h, hipMemcpyDeviceToHost));
         return MSLAM_HIP_OK;
     }

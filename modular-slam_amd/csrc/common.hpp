@@ -36,8 +36,30 @@ struct Geometry
     int n_cells;
     int frame0;    // first frame this launch works on (blockIdx is relative to it)
     unsigned slab; // bytes per frame (all levels)
+    int blur_tiled; // the blurred slab is stored in kTileW x kTileH pixel tiles (tiled_off) instead of rows: set when every level comes from k_level.hip
     LevelGeom lv[kMaxLevels];
 };
+
+// Tiled plane layout: a level plane of pitch p (a multiple of kTileW) and h rows (stored as whole tile rows) is cut into
+// tiles of kTileW pixels x kTileH rows = 128 bytes = one cache line, tiles of a tile row side by side, rows of a tile one
+// after the other.  A window of r rows x c columns then touches about (r/kTileH + 1)(c/kTileW + 1) lines instead of
+// r (1 + c/128): what k_describe's window gathers pay for.
+#ifndef MSLAM_TILE_W
+#define MSLAM_TILE_W 64
+#endif
+constexpr int kTileW = MSLAM_TILE_W, kTileH = 128 / kTileW;
+constexpr int kTileWLog = kTileW == 64 ? 6 : kTileW == 32 ? 5 : 4, kTileHLog = 7 - kTileWLog;
+static_assert(kTileW == 16 || kTileW == 32 || kTileW == 64, "tile width");
+__host__ __device__ __forceinline__ unsigned tiled_off(unsigned pitch, int x, int y)
+{
+    return (unsigned)(y >> kTileHLog) * (pitch * (unsigned)kTileH) + (unsigned)(x >> kTileWLog) * 128u +
+           (unsigned)(y & (kTileH - 1)) * (unsigned)kTileW + (unsigned)(x & (kTileW - 1));
+}
+// byte step from row y to row y + 1 of the same column
+__host__ __device__ __forceinline__ unsigned tiled_row_step(unsigned pitch, int y)
+{
+    return ((y + 1) & (kTileH - 1)) != 0 ? (unsigned)kTileW : pitch * (unsigned)kTileH - (unsigned)((kTileH - 1) * kTileW);
+}
 
 // FAST cell: a sub-image [x0, x0+cw) x [y0, y0+ch) of one level (:880-905).
 struct CellDesc
@@ -131,6 +153,7 @@ struct GrayBlurArgs
     int k6;             // rows per block = 6 k6 + 2
     unsigned dump_off;  // offset (from the slab's first byte) of the 256 pad bytes that end every frame's slab
     int waves_per_xcd;  // filled in by the launcher
+    int blur_tiled;     // Geometry::blur_tiled
     BlurK bk;
 };
 void launch_gray_blur(const GrayBlurArgs& a, hipStream_t s);
@@ -152,6 +175,7 @@ struct ResizeBlurArgs
     int exact;     // 0: INTER_LINEAR, 1: INTER_LINEAR_EXACT
     unsigned dump_off; // offset of the 256 pad bytes that end every frame's slab
     int waves_per_xcd; // filled in by the launcher
+    int blur_tiled;    // Geometry::blur_tiled
     BlurK bk;
 };
 void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s);

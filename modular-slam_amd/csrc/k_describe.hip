@@ -10,6 +10,7 @@
 // the reference expression order; cvRound = round-half-even, cvFloor = floor.
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 #include "../../include/mslam_orb_pattern.h"
 #include "../../include/mslam_sincos.h"
 
@@ -77,6 +78,8 @@ __device__ __forceinline__ float util_sin(float v)
 constexpr int kPatchR = 18;               // the rotated pattern reaches |18| (its radius is 18.38; the reference keeps a 19-px border)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 12;              // 48-byte rows: 37 needed bytes from a 16-byte aligned start, or from 12 bytes past one
+constexpr int kPatchDwT = 16;             // tiled blurred plane (below): up to four aligned 16-byte chunks per row
+constexpr int kPatchBufsT = 4;            // ... and a 4-slot ring (37 x 64 bytes per slot: 37.9 KB per workgroup, 4 workgroups per CU)
 constexpr int kPatchBufs = 5;            // LDS patch ring per wave: one being sampled, four in flight (3 / 4 / 5 slots of 1776 bytes: 0.505 / 0.493 / 0.486 ms per 500 frames; 35.5 KB per workgroup = 4 workgroups per CU: with 5 (4 slots) the frames in flight per XCD outgrow its L2 and the memory-side reads rise from 1.9 to 2.2 MB per frame)
 constexpr int kBlocksPerFrame = 32;
 
@@ -132,9 +135,16 @@ __device__ __forceinline__ void wave_sum_dpp2(int a, int b, int& ra, int& rb)
 constexpr int kBatch = 16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// TILED: the blurred plane is stored in kTileW x kTileH pixel tiles (one 128-byte line each, common.hpp: tiled_off) — a
+// 37-row patch then touches fewer lines than its 37 rows x 1.4 (row-major: every patch row is a line of its own, and what
+// this kernel pays for is lines).  A tiled row can only be fetched in aligned 16-byte chunks: three when the patch starts at
+// byte <= 11 of its first chunk, else four (LDS row pitch 48 / 64 bytes, wave-uniform per keypoint).
+template <bool TILED>
 __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bpf)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t patch[4][kPatchBufs][kPatchRows * kPatchDw];
+    constexpr int kBufs = TILED ? kPatchBufsT : kPatchBufs;
+    constexpr int kSlotDw = kPatchRows * (TILED ? kPatchDwT : kPatchDw);
+    __shared__ __attribute__((aligned(16))) uint32_t patch[4][kBufs][kSlotDw];
 
     // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, so all kBlocksPerFrame
     // workgroups of a frame are given ids with the same (id & 7): the two level slabs of a frame (1.9 MB)
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
         //         batch; the per-keypoint phases then only broadcast lane k's registers (v_readlane).
         uint32_t my_kp = 0;
         int my_level = 0;
-        uint32_t my_doff = 0, my_poff = 0, my_pitch = 16, my_sh = 0;
+        uint32_t my_doff = 0, my_poff = 0, my_pitch = 16, my_sh = 0, my_pxy = 0;
         float my_scale = 1.f, my_resp = 0.f;
         {
             const int idx = base + lane * kStr; // position in the frame's concatenated keypoint list (:787-808)
@@ -240,7 +250,10 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 my_resp = a.sel_resp ? a.sel_resp[si] : (float)kp_score(my_kp);
                 const int px = kp_x(my_kp) + kBorder, py = kp_y(my_kp) + kBorder; // :966-967
                 my_doff = lofs + (uint32_t)(py - 15) * my_pitch + (uint32_t)((px - 15) & ~15);
-                my_poff = lofs + (uint32_t)(py - kPatchR) * my_pitch + (uint32_t)((px - kPatchR) & ~15);
+                if(TILED) // level offset; the patch's first 16-byte column and first row ride in my_pxy
+                    my_poff = lofs, my_pxy = (uint32_t)((px - kPatchR) & ~15) | ((uint32_t)(py - kPatchR) << 16);
+                else
+                    my_poff = lofs + (uint32_t)(py - kPatchR) * my_pitch + (uint32_t)((px - kPatchR) & ~15);
                 my_sh = (uint32_t)((px - 15) & 15) | ((uint32_t)((px - kPatchR) & 15) << 4);
             }
         }
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 my_m10 = lane == k ? t10 : my_m10;
                 my_m01 = lane == k ? t01 : my_m01;
             };
-            constexpr int kDepthA = kPatchBufs - 1;
+            constexpr int kDepthA = kBufs - 1;
 #pragma unroll
             for(int i = 0; i < kDepthA; ++i)
                 if(i < n_here)
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
             {
                 const int younger = min(kDepthA, n_here - 1 - k); // windows issued after window k: 2 DMAs each
                 if(k + kDepthA < n_here)
-                    dma_disc(k + kDepthA, (k + kDepthA) % kPatchBufs);
+                    dma_disc(k + kDepthA, (k + kDepthA) % kBufs);
                 if(younger >= 4)
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
                 else if(younger == 3)
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 else
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
                 __builtin_amdgcn_wave_barrier();
-                reduce(k, k % kPatchBufs);
+                reduce(k, k % kBufs);
                 __builtin_amdgcn_wave_barrier(); // the reads are done before the slot is refilled
             }
         }
@@ -331,7 +344,46 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
             // the chunks start 12 bytes past the aligned one (bytes [12, 60) of the row's 64-byte span hold the 37 needed
             // ones): LDS-DMA b128 only needs a 4-byte aligned global address.  (A 12-byte DMA would not do: b96 writes its
             // 12 bytes at a 16-byte lane stride in LDS.)
-            bsrc += (bc(my_sh, k) >> 4) > 11u ? 12 : 0;
+            const uint32_t shp = (bc(my_sh, k) >> 4) & 15u;
+            if(TILED)
+            {
+                // chunk (row, c) of the patch = bytes [xa + 16 c, + 16) of image row ya + row (common.hpp: tiled_off)
+                const uint32_t pxy = bc(my_pxy, k);
+                const uint32_t xa = pxy & 0xFFFFu, ya = pxy >> 16;
+                const uint32_t pitchT = pitch * (uint32_t)kTileH;
+                auto chunk_off = [&](uint32_t row, uint32_t c) {
+                    const uint32_t x = xa + 16u * c, yy = ya + row;
+                    return __umul24(yy >> kTileHLog, pitchT) + ((x >> kTileWLog) << 7) + ((yy & (uint32_t)(kTileH - 1)) << kTileWLog) +
+                           (x & (uint32_t)(kTileW - 1));
+                };
+                if(shp > 11u)
+                {
+#pragma unroll
+                    for(int q = 0; q < 3; ++q)
+                    {
+                        const uint32_t t = (uint32_t)lane + 64u * q;
+                        if(t < (uint32_t)(kPatchRows * 4))
+                            __builtin_amdgcn_global_load_lds(
+                                (const __attribute__((address_space(1))) void*)(bsrc + chunk_off(t >> 2, t & 3u)),
+                                (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for(int q = 0; q < 2; ++q)
+                    {
+                        const uint32_t t = (uint32_t)lane + 64u * q;
+                        const uint32_t row = (t * 21846u) >> 16; // t / 3
+                        if(t < (uint32_t)(kPatchRows * 3))
+                            __builtin_amdgcn_global_load_lds(
+                                (const __attribute__((address_space(1))) void*)(bsrc + chunk_off(row, t - 3u * row)),
+                                (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                    }
+                }
+                return;
+            }
+            bsrc += shp > 11u ? 12 : 0;
 #pragma unroll
             for(int q = 0; q < 2; ++q)
             {
@@ -343,7 +395,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                         (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
             }
         };
-        constexpr int kDepth = kPatchBufs - 1; // patches in flight beside the one being sampled
+        constexpr int kDepth = kBufs - 1; // patches in flight beside the one being sampled
 #pragma unroll
         for(int i = 0; i < kDepth; ++i)
             if(i < n_here)
@@ -389,22 +441,38 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 asm volatile("" : "+v"(ca2), "+v"(sa2)); // keep them vector register pairs (not re-associated onto the scalars)
                 const f32x2 magic = f32x2{12582912.f, 12582912.f};
                 const uint8_t* lp = reinterpret_cast<const uint8_t*>(patch[wave][buf]);
-                const uint32_t shp = bc(my_sh, k) >> 4;
-                // 48-byte row pitch; the row starts at the aligned chunk (shp <= 11) or 12 bytes past it (see dma_patch)
-                const uint32_t ctr_off = (uint32_t)(kPatchR * 48 + kPatchR) + (shp <= 11u ? shp : shp - 12u) - 49u * 0x4B400000u;
+                const uint32_t shp = (bc(my_sh, k) >> 4) & 15u;
                 unsigned long long bits[4];
+                // row-major plane: 48-byte row pitch; the row starts at the aligned chunk (shp <= 11) or 12 bytes past it (see
+                // dma_patch).  Tiled plane: the row always starts at the aligned chunk; 48-byte pitch when shp <= 11, else 64.
+                auto sample = [&](auto wide) {
+                    constexpr bool WIDE = decltype(wide)::value;
+                    constexpr uint32_t P = WIDE ? 64u : 48u;
+                    const uint32_t ctr_off = (uint32_t)(kPatchR * P + kPatchR) + (TILED || shp <= 11u ? shp : shp - 12u) - (P + 1u) * 0x4B400000u;
 #pragma unroll
-                for(int t = 0; t < 4; ++t)
+                    for(int t = 0; t < 4; ++t)
+                    {
+                        // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
+                        const f32x2 rr = (patX[t] * sa2 + patY[t] * ca2) + magic;
+                        const f32x2 cc = (patX[t] * ca2 - patY[t] * sa2) + magic;
+                        const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y);
+                        // row * P + byte in row
+                        const uint32_t i0 = WIDE ? (r0 << 6) + __float_as_uint(cc.x) + ctr_off : (r0 << 5) + (r0 << 4) + __float_as_uint(cc.x) + ctr_off;
+                        const uint32_t i1 = WIDE ? (r1 << 6) + __float_as_uint(cc.y) + ctr_off : (r1 << 5) + (r1 << 4) + __float_as_uint(cc.y) + ctr_off;
+                        const int v0 = lp[i0];
+                        const int v1 = lp[i1];
+                        bits[t] = __ballot(v0 < v1);
+                    }
+                };
+                if(TILED && shp > 11u)
                 {
-                    // GET_VALUE (:603-605): row = cvRound(x*sin + y*cos), col = cvRound(x*cos - y*sin)
-                    const f32x2 rr = (patX[t] * sa2 + patY[t] * ca2) + magic;
-                    const f32x2 cc = (patX[t] * ca2 - patY[t] * sa2) + magic;
-                    const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y);
-                    const uint32_t i0 = (r0 << 5) + (r0 << 4) + __float_as_uint(cc.x) + ctr_off; // row * 48 + byte in row
-                    const uint32_t i1 = (r1 << 5) + (r1 << 4) + __float_as_uint(cc.y) + ctr_off;
-                    const int v0 = lp[i0];
-                    const int v1 = lp[i1];
-                    bits[t] = __ballot(v0 < v1);
+                    asm volatile("");
+                    sample(std::true_type{});
+                }
+                else
+                {
+                    asm volatile("");
+                    sample(std::false_type{});
                 }
                 if(lane < 4)
                 {
@@ -415,7 +483,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                     reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k * kStr) * 32)[lane] = w;
                 }
             };
-            static_assert(kPatchBufs >= 2 && kPatchBufs <= 5, "the vmcnt immediates of phases A and C cover up to four younger windows");
+            static_assert(kBufs >= 2 && kBufs <= 5, "the vmcnt immediates of phases A and C cover up to four younger windows");
             static_assert(kDepth >= 1 && kDepth <= 5, "the vmcnt immediates below cover up to 5 patches in flight");
             for(int k = 0; k < n_here; ++k)
             {
@@ -424,7 +492,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 // wait a little longer than necessary)
                 const int younger = min(kDepth, n_here - 1 - k);
                 if(k + kDepth < n_here)
-                    dma_patch(k + kDepth, (k + kDepth) % kPatchBufs); // its ring slot was sampled in iteration k - 1
+                    dma_patch(k + kDepth, (k + kDepth) % kBufs); // its ring slot was sampled in iteration k - 1
                 // (a patch is 2 or 3 instructions: counting 2 for every younger one is the safe side)
                 if(younger >= 5)
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 10);
@@ -439,7 +507,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 else
                     __builtin_amdgcn_s_waitcnt(0x0F70 | 0);
                 __builtin_amdgcn_wave_barrier();
-                describe(k, k % kPatchBufs);
+                describe(k, k % kBufs);
                 __builtin_amdgcn_wave_barrier(); // the gathers are done before the slot is refilled
             }
         }
@@ -464,7 +532,10 @@ void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_fra
     // a handful of frames (the synchronous single-frame call): twice the workgroups per frame, half the keypoints per wave
     const int bpf = bpf_env ? bpf_env : n_frames < 8 ? 2 * kBlocksPerFrame : kBlocksPerFrame;
     const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)bpf;
-    hipLaunchKernelGGL(k_describe, dim3(grid), dim3(256), 0, s, gg, aa, bpf);
+    if(g.blur_tiled)
+        hipLaunchKernelGGL(k_describe<true>, dim3(grid), dim3(256), 0, s, gg, aa, bpf);
+    else
+        hipLaunchKernelGGL(k_describe<false>, dim3(grid), dim3(256), 0, s, gg, aa, bpf);
 }
 
 } // namespace mslam

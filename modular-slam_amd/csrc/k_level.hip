@@ -155,6 +155,11 @@ struct Bgr3
 };
 
 // ---- level 0: gray + blur --------------------------------------------------------------------------------------------
+// TILED: the blurred plane is written in kTileW x kTileH pixel tiles (common.hpp: tiled_off; k_describe's patches then
+// touch fewer lines).  A lane's dword keeps its place inside the tile row; going down one row is +kTileW bytes, or on to
+// the next tile row after a tile's last row — a wave-uniform step, applied to productive lanes only (halo lanes stay on
+// their dump word).
+template <bool TILED>
 __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -183,6 +188,9 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
     const uint32_t col_v = (uint32_t)(f + a.frame0) * a.slab + 4u * (uint32_t)q;
     uint32_t raw_v = productive ? col_v + (uint32_t)(y0 - 3) * (uint32_t)a.pitch : dump_v;  // raw row of block row i = 0
     uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.pitch : dump_v; // blurred row of block row i = 0 (used from i = 6 on)
+    if(TILED)
+        blur_v = productive ? (uint32_t)(f + a.frame0) * a.slab + tiled_off((unsigned)a.pitch, 4 * q, y0 - 6) : dump_v;
+    const uint32_t prod01 = productive ? 1u : 0u;
     const uint32_t row_bytes = (uint32_t)a.W * 3u;
 
     // buffer loads: the wave-uniform row offset rides in the scalar offset operand, the lane's offset in the vector one —
@@ -215,7 +223,10 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
         if(EMIT)
             *reinterpret_cast<uint32_t*>(a.blur + blur_v) = o;
         raw_v += pitch_v;
-        blur_v += pitch_v;
+        if(TILED)
+            blur_v = __umul24(prod01, tiled_row_step((unsigned)a.pitch, y0 - 6 + i)) + blur_v;
+        else
+            blur_v += pitch_v;
     };
     using std::integral_constant;
 #define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
@@ -261,7 +272,7 @@ struct HRow
 // NEED: bit k set = pixel k of a quad may take its (S[x], S[x+1]) pair from window dwords (1,2) instead of (0,1) — a
 // compile-time superset of the level's mask (at scale 1.2 only the fourth pixel ever does), so that the other pixels carry
 // no per-lane selects
-template <bool EXACT, int NEED>
+template <bool EXACT, int NEED, bool TILED>
 __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -294,6 +305,9 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     const uint32_t col_v = (uint32_t)(f + a.frame0) * a.slab + (uint32_t)a.dst_off + 4u * (uint32_t)qx;
     uint32_t raw_v = productive ? col_v + (uint32_t)(y0 - 3) * (uint32_t)a.dpitch : dump_v;
     uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.dpitch : dump_v;
+    if(TILED) // (see k_gray_blur)
+        blur_v = productive ? (uint32_t)(f + a.frame0) * a.slab + (uint32_t)a.dst_off + tiled_off((unsigned)a.dpitch, 4 * qx, y0 - 6) : dump_v;
+    const uint32_t prod01 = productive ? 1u : 0u;
     const uint8_t* src_lv = a.pyr + a.src_off;
 
     const BufRsrc src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, -1, 0x00020000);
@@ -428,7 +442,10 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
         if(EMIT)
             *reinterpret_cast<uint32_t*>(a.blur + blur_v) = o;
         raw_v += pitch_v;
-        blur_v += pitch_v;
+        if(TILED)
+            blur_v = __umul24(prod01, tiled_row_step((unsigned)a.dpitch, y0 - 6 + i)) + blur_v;
+        else
+            blur_v += pitch_v;
     };
     using std::integral_constant;
 #define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
@@ -461,7 +478,8 @@ void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s)
     b.waves_per_xcd = ((n_waves + 31) / 32) * 4; // whole workgroups per XCD
     dim3 grid(8 * (b.waves_per_xcd / 4), (a.dh + R - 1) / R);
     const int need = (a.need_mask & ~8) == 0 ? (a.need_mask ? 8 : 0) : (a.need_mask & ~12) == 0 ? 12 : 15;
-#define MSLAM_RB(E, N) hipLaunchKernelGGL((k_resize_blur<E, N>), grid, dim3(256), 0, s, b)
+#define MSLAM_RB(E, N) do { if(a.blur_tiled) hipLaunchKernelGGL((k_resize_blur<E, N, true>), grid, dim3(256), 0, s, b); \
+                           else hipLaunchKernelGGL((k_resize_blur<E, N, false>), grid, dim3(256), 0, s, b); } while(0)
     if(a.exact)
     {
         if(need == 0) MSLAM_RB(true, 0); else if(need == 8) MSLAM_RB(true, 8); else if(need == 12) MSLAM_RB(true, 12); else MSLAM_RB(true, 15);
@@ -480,7 +498,10 @@ void launch_gray_blur(const GrayBlurArgs& a, hipStream_t s)
     GrayBlurArgs b = a;
     b.waves_per_xcd = ((n_waves + 31) / 32) * 4; // whole workgroups per XCD
     dim3 grid(8 * (b.waves_per_xcd / 4), (a.H + R - 1) / R);
-    hipLaunchKernelGGL(k_gray_blur, grid, dim3(256), 0, s, b);
+    if(a.blur_tiled)
+        hipLaunchKernelGGL(k_gray_blur<true>, grid, dim3(256), 0, s, b);
+    else
+        hipLaunchKernelGGL(k_gray_blur<false>, grid, dim3(256), 0, s, b);
 }
 
 } // namespace mslam

@@ -18,6 +18,8 @@ def test_kernel_names_map_to_stages():
     assert m("mslam::k_blur2") == "blur" and m("mslam::k_fast_cells") == "fast" and m("mslam::k_zero_u32") == "fast"
     assert m("void mslam::k_match_knn2_fp4<4, false>") == "match_knn2" and m("void mslam::k_match_knn2<8, 1, 8>") == "match_knn2"
     assert m("mslam::k_describe") == "describe" and m("mslam::k_quadtree_big") == "quadtree"
+    assert m("void mslam::k_describe<true>") == "describe" and m("void mslam::k_gray_blur<true>") == "gray"
+    assert m("void mslam::k_resize_blur<false, 8, true>") == "resize" and m("void mslam::k_match_knn2_fp4<4, false>") == "match_knn2"
     assert m("__amd_rocclr_copyBuffer") is None
 
 
