@@ -15,11 +15,16 @@
 // carries the list position of its node.  The per-leaf winner ("first maximum", :1142-1149) is an
 // atomicMax over (score, -original index).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace mslam
 {
 
-constexpr int QT = 512;           // threads per workgroup
+constexpr int QT = 512;           // threads per workgroup (k_quadtree's small class: kSmallQT)
+// k_quadtree's classes: a (level, frame) pair runs in the smallest instance that holds its candidates — the passes are
+// latency-bound, so what sets the throughput is how many workgroups share a CU (LDS: 37 bytes per candidate)
+constexpr int kSmallKp = 512, kSmallQT = 256; // 19 KB, 256 threads: 8 workgroups per CU
+constexpr int kMidKp = 1024, kMidQT = 512;    // 38 KB, 512 threads: 4 workgroups per CU (the large class: 74 KB, 2 per CU)
 constexpr int kLdsKp = 2048;      // levels with at most this many candidates keep ALL working arrays in LDS
 constexpr int kMaxCellsPerLevel = 2048;
 constexpr int kBigNodes = 4096;   // k_quadtree_big: node arrays in LDS up to this many list nodes,
@@ -49,6 +54,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 
 // exclusive scan of one value per thread across the workgroup; returns the exclusive prefix, `total`
 // receives the workgroup sum.  Two barriers; `s` may be reused right after return.
+template <int NT>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Scan& s, uint32_t& total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -58,7 +64,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Scan& s, uint32_
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for(int w = 0; w < QT / 64; ++w)
+    for(int w = 0; w < NT / 64; ++w)
     {
         const uint32_t x = s.wsum[w];
         if(w < wave)
@@ -71,6 +77,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Scan& s, uint32_
 }
 
 // the same for two values at once (one pair of barriers)
+template <int NT>
 __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, Scan& s, Scan& s2, uint32_t& exa, uint32_t& exb,
                                                  uint32_t& tota, uint32_t& totb)
 {
@@ -84,7 +91,7 @@ __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, Scan& s
     __syncthreads();
     uint32_t ba = 0, bb = 0, ta = 0, tb = 0;
 #pragma unroll
-    for(int w = 0; w < QT / 64; ++w)
+    for(int w = 0; w < NT / 64; ++w)
     {
         const uint32_t x = s.wsum[w], y = s2.wsum[w];
         if(w < wave)
@@ -152,7 +159,7 @@ struct GlobalStore
 
 // Everything after the candidate count is known.  Instantiated twice and force-inlined so that, in the
 // LDS instance, every working array is a known LDS object (ds_* instructions instead of flat_*).
-template <class S>
+template <class S, int NT>
 __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, const LevelGeom& lv, size_t frame,
                                          size_t slot, int tid, uint32_t N, int n_cells, const uint32_t* cell_off,
                                          uint32_t* cand, uint32_t* g_cand, typename S::idx_t* kp_node, uint2* nodes,
@@ -165,7 +172,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
     constexpr uint32_t kNoNode = (uint32_t)(idx_t)~(idx_t)0;
 
     const uint32_t* ckp = a.cell_kp + (frame * g.n_cells + lv.cell_base) * (size_t)kCellCap;
-    for(uint32_t j = tid; j < N; j += QT)
+    for(uint32_t j = tid; j < N; j += NT)
     {
         int lo = 0, hi = n_cells - 1; // last cell with cell_off <= j
         while(lo < hi)
@@ -188,7 +195,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
     if(tid < kMaxInitNodes)
         init_cnt[tid] = 0;
     __syncthreads();
-    for(uint32_t k = tid; k < N; k += QT)
+    for(uint32_t k = tid; k < N; k += NT)
     {
         const uint32_t p = cand[k];
         const unsigned ix = (unsigned)((double)(float)kp_x(p) / lv.delta_x);
@@ -221,7 +228,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
         sh_n = n0;
     }
     __syncthreads();
-    for(uint32_t k = tid; k < N; k += QT)
+    for(uint32_t k = tid; k < N; k += NT)
     {
         const uint32_t idx = kp_node[k];
         if(idx != kNoNode)
@@ -237,7 +244,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
     for(int pass = 0; pass < kMaxPasses && n > 0; ++pass)
     {
         // a. which nodes divide (:1002)
-        for(uint32_t pos = tid; pos < n; pos += QT)
+        for(uint32_t pos = tid; pos < n; pos += NT)
         {
             int bx, by, ex, ey;
             unpack_node(nodes[pos], bx, by, ex, ey);
@@ -249,7 +256,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
         }
         __syncthreads();
         // b. count keypoints per child (:340-352)
-        for(uint32_t k = tid; k < N; k += QT)
+        for(uint32_t k = tid; k < N; k += NT)
         {
             const uint32_t pos = kp_node[k];
             if(pos == kNoNode || !(ninfo[pos] & 1u))
@@ -263,7 +270,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
         __syncthreads();
         // c. list positions after this pass
         uint32_t D = 0, U = 0;
-        for(uint32_t base = 0; base < n; base += QT)
+        for(uint32_t base = 0; base < n; base += NT)
         {
             const uint32_t pos = base + tid;
             uint32_t nchild = 0, und = 0, mask = 0, div = 0;
@@ -280,7 +287,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
                     und = 1;
             }
             uint32_t totD, totU, exD, exU;
-            block_excl_scan2(nchild, und, scan, scan2, exD, exU, totD, totU);
+            block_excl_scan2<NT>(nchild, und, scan, scan2, exD, exU, totD, totU);
             if(pos < n)
             {
                 ninfo[pos] = (typename S::info_t)(div | (mask << 1));
@@ -295,7 +302,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
             return false; // (workgroup-uniform) the next list does not fit the LDS node arrays
         // d. materialise the new list; e. re-point the keypoints.  Both only read what step c wrote
         //    (nbase = scan prefix, ninfo = divide flag + child mask) and T, so they share one phase.
-        for(uint32_t pos = tid; pos < n; pos += QT)
+        for(uint32_t pos = tid; pos < n; pos += NT)
         {
             const uint32_t info = ninfo[pos];
             if(info & 1u)
@@ -318,7 +325,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
                 ncnt2[np] = ncnt[pos];
             }
         }
-        for(uint32_t k = tid; k < N; k += QT)
+        for(uint32_t k = tid; k < N; k += NT)
         {
             const uint32_t pos = kp_node[k];
             if(pos == kNoNode)
@@ -356,10 +363,10 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
         atomicOr(a.flags, kFlagQuadNoConverge);
 
     // ---- 3. winner per node, emitted in list order (:1128-1155)
-    for(uint32_t pos = tid; pos < n; pos += QT)
+    for(uint32_t pos = tid; pos < n; pos += NT)
         best[pos] = 0;
     __syncthreads();
-    for(uint32_t k = tid; k < N; k += QT)
+    for(uint32_t k = tid; k < N; k += NT)
     {
         const uint32_t pos = kp_node[k];
         if(pos == kNoNode)
@@ -367,7 +374,7 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
         atomicMax(&best[pos], ((uint32_t)kp_score(cand[k]) << 24) | (0xFFFFFFu - k));
     }
     __syncthreads();
-    for(uint32_t pos = tid; pos < n; pos += QT)
+    for(uint32_t pos = tid; pos < n; pos += NT)
     {
         const uint32_t k = 0xFFFFFFu - ((S::kLds ? best[pos] : ld_atomic(&best[pos])) & 0xFFFFFFu);
         sel[pos] = cand[k];
@@ -378,16 +385,17 @@ __device__ __forceinline__ bool quad_run(const Geometry& g, const QuadArgs& a, c
 }
 
 // gather step shared by both kernels: candidate offsets per cell (-> cell_off[0 .. n_cells]), returns N
+template <int NT>
 __device__ __forceinline__ uint32_t quad_cell_offsets(const uint32_t* ccnt, int n_cells, uint32_t* cell_off, Scan& scan)
 {
     const int tid = threadIdx.x;
     uint32_t running = 0;
-    for(int base = 0; base < n_cells; base += QT)
+    for(int base = 0; base < n_cells; base += NT)
     {
         const int i = base + tid;
         const uint32_t v = i < n_cells ? ccnt[i] : 0u;
         uint32_t tot;
-        const uint32_t ex = block_excl_scan(v, scan, tot);
+        const uint32_t ex = block_excl_scan<NT>(v, scan, tot);
         if(i < n_cells)
             cell_off[i] = running + ex;
         running += tot;
@@ -398,19 +406,33 @@ __device__ __forceinline__ uint32_t quad_cell_offsets(const uint32_t* ccnt, int 
     return running;
 }
 
-__global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a, unsigned big_levels)
+// KP / NT: LDS capacity (candidates) and threads of the instance, CLS its class (0 small, 1 mid, 2 large).  The three
+// instances are launched on the same grid, one after the other; each takes the (level, frame) pairs of its class and leaves
+// the others alone (a few microseconds for the candidate count).  On a 640x480 pyramid (about 990 ... 240 candidates on
+// levels 0 ... 7) four levels run in the small class and four in the mid one.
+__device__ __forceinline__ int quad_class(uint32_t N, int n_cells, unsigned classes)
+{
+    if((classes & 1u) && N <= (uint32_t)kSmallKp && n_cells <= 2 * kSmallKp - 1)
+        return 0;
+    if((classes & 2u) && N <= (uint32_t)kMidKp && n_cells <= 2 * kMidKp - 1)
+        return 1;
+    return 2;
+}
+template <int KP, int NT, int CLS>
+__global__ __launch_bounds__(NT) void k_quadtree(Geometry g, QuadArgs a, unsigned big_levels)
 {
     __shared__ Scan scan, scan2;
-    // LDS working set of the common case (N <= kLdsKp): 74 KB, so two workgroups share a CU.
-    __shared__ uint32_t l_cand[kLdsKp];
-    __shared__ uint2 l_nodes_a[kLdsKp], l_nodes_b[kLdsKp]; // l_nodes_b doubles as the cell offset table of step 0
-    __shared__ uint32_t l_cc[kLdsKp * 2];                   // packed child counters; reused for the winners
-    __shared__ uint16_t l_kp_node[kLdsKp], l_ncnt_a[kLdsKp], l_ncnt_b[kLdsKp], l_nbase[kLdsKp];
-    __shared__ uint8_t l_ninfo[kLdsKp];
+    __shared__ uint32_t l_cand[KP];
+    __shared__ uint2 l_nodes_a[KP], l_nodes_b[KP]; // l_nodes_b doubles as the cell offset table of step 0
+    __shared__ uint32_t l_cc[KP * 2];               // packed child counters; reused for the winners
+    __shared__ uint16_t l_kp_node[KP], l_ncnt_a[KP], l_ncnt_b[KP], l_nbase[KP];
+    __shared__ uint8_t l_ninfo[KP];
     __shared__ uint32_t init_cnt[kMaxInitNodes];
     __shared__ uint32_t init_pos[kMaxInitNodes];
     __shared__ uint32_t sh_n;
-    static_assert(sizeof(l_nodes_b) >= (kMaxCellsPerLevel + 1) * sizeof(uint32_t), "cell offsets must fit");
+    constexpr int kCellsFit = 2 * KP - 1; // cells whose offsets (n_cells + 1 dwords) fit l_nodes_b
+    static_assert(CLS != 2 || kCellsFit >= kMaxCellsPerLevel, "cell offsets must fit");
+    const unsigned classes = big_levels >> 30; // which smaller instances were launched (bits 30, 31)
     uint32_t* cell_off = reinterpret_cast<uint32_t*>(l_nodes_b);
 
     // Workgroups go to the 8 XCDs round-robin by linear id = frame * n_levels + blockIdx.x.  With the usual 8
@@ -428,8 +450,12 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a, unsigne
     // ---- 0. gather this level's candidates in the reference's order: cells row-major, then the
     //         row-major order inside each cell (:878-951)
     const int n_cells = lv.n_cells;
+    if(n_cells > kCellsFit)
+        return; // (a larger class takes the level)
     const uint32_t* ccnt = a.cell_cnt + frame * g.n_cells + lv.cell_base;
-    const uint32_t N = quad_cell_offsets(ccnt, n_cells, cell_off, scan);
+    const uint32_t N = quad_cell_offsets<NT>(ccnt, n_cells, cell_off, scan);
+    if(quad_class(N, n_cells, classes) != CLS)
+        return; // another instance's pair
     if(N > (uint32_t)a.cand_cap)
     {
         if(tid == 0)
@@ -448,17 +474,17 @@ __global__ __launch_bounds__(QT) void k_quadtree(Geometry g, QuadArgs a, unsigne
             a.sel_cnt[slot] = 0;
         return;
     }
-    if(N <= (uint32_t)kLdsKp)
-        quad_run<LdsStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, l_cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
-                           l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, l_cc, l_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
+    if(N <= (uint32_t)KP)
+        quad_run<LdsStore, NT>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, l_cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
+                               l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, l_cc, l_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
     else if((big_levels >> level) & 1u)
         return; // k_quadtree_big, launched right behind this kernel, takes this (level, frame)
     else
-        quad_run<GlobalStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, a.kp_node + slot * cap,
-                              a.nodes_a + slot * cap, a.nodes_b + slot * cap, a.ncnt_a + slot * cap,
-                              a.ncnt_b + slot * cap, a.ninfo + slot * cap, a.best + slot * cap,
-                              a.child_cnt + slot * cap * 4, a.best + slot * cap, sel, scan, scan2, init_cnt, init_pos,
-                              sh_n);
+        quad_run<GlobalStore, NT>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, a.kp_node + slot * cap,
+                                  a.nodes_a + slot * cap, a.nodes_b + slot * cap, a.ncnt_a + slot * cap,
+                                  a.ncnt_b + slot * cap, a.ninfo + slot * cap, a.best + slot * cap,
+                                  a.child_cnt + slot * cap * 4, a.best + slot * cap, sel, scan, scan2, init_cnt, init_pos,
+                                  sh_n);
 }
 
 // Second kernel for the levels of large images: the (level, frame) pairs k_quadtree left alone because they have more
@@ -499,19 +525,19 @@ __global__ __launch_bounds__(QT) void k_quadtree_big(Geometry g, QuadArgs a, uns
     uint32_t* sel = a.sel + slot * cap;
     const int n_cells = lv.n_cells;
     const uint32_t* ccnt = a.cell_cnt + frame * g.n_cells + lv.cell_base;
-    const uint32_t N = quad_cell_offsets(ccnt, n_cells, cell_off, scan);
+    const uint32_t N = quad_cell_offsets<QT>(ccnt, n_cells, cell_off, scan);
     if(N <= (uint32_t)kLdsKp || N > (uint32_t)a.cand_cap)
         return; // done (or flagged) by k_quadtree
     bool done = false;
     if(N <= (uint32_t)kBigKp)
-        done = quad_run<BigStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
+        done = quad_run<BigStore, QT>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, l_kp_node, l_nodes_a, l_nodes_b,
                                   l_ncnt_a, l_ncnt_b, l_ninfo, l_nbase, l_cc, l_cc, sel, scan, scan2, init_cnt, init_pos, sh_n);
     if(!done)
     {
         __syncthreads();
         // the cell offsets were overwritten (they share storage with the node arrays): rebuild them
-        quad_cell_offsets(ccnt, n_cells, cell_off, scan);
-        quad_run<GlobalStore>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, a.kp_node + slot * cap,
+        quad_cell_offsets<QT>(ccnt, n_cells, cell_off, scan);
+        quad_run<GlobalStore, QT>(g, a, lv, frame, slot, tid, N, n_cells, cell_off, cand, cand, a.kp_node + slot * cap,
                               a.nodes_a + slot * cap, a.nodes_b + slot * cap, a.ncnt_a + slot * cap,
                               a.ncnt_b + slot * cap, a.ninfo + slot * cap, a.best + slot * cap,
                               a.child_cnt + slot * cap * 4, a.best + slot * cap, sel, scan, scan2, init_cnt, init_pos,
@@ -528,7 +554,14 @@ void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_fra
     for(int l = 0; l < g.n_levels; ++l)
         if(g.lv[l].w * g.lv[l].h > kBigMinPixels)
             big_levels |= 1u << l;
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT), 0, s, gg, a, big_levels);
+    // MSLAM_HIP_QUAD_CLASSES: bit 0 = small instance, bit 1 = mid instance (default both; 0 = the large instance alone)
+    static const unsigned classes = [] { const char* e = getenv("MSLAM_HIP_QUAD_CLASSES"); return e ? (unsigned)atoi(e) & 3u : 3u; }();
+    const unsigned bl = big_levels | (classes << 30);
+    hipLaunchKernelGGL((k_quadtree<kLdsKp, QT, 2>), grid, dim3(QT), 0, s, gg, a, bl);
+    if(classes & 2u)
+        hipLaunchKernelGGL((k_quadtree<kMidKp, kMidQT, 1>), grid, dim3(kMidQT), 0, s, gg, a, bl);
+    if(classes & 1u)
+        hipLaunchKernelGGL((k_quadtree<kSmallKp, kSmallQT, 0>), grid, dim3(kSmallQT), 0, s, gg, a, bl);
     if(big_levels != 0)
     {
         constexpr size_t lds = (size_t)kBigNodes * (8 + 8 + 8 + 2 + 2 + 2 + 1) + (size_t)kBigKp * 2;
