@@ -665,7 +665,7 @@ static int create_impl(mslam_hip_ctx* c)
             c->level_k6_small = ks ? std::max(1, atoi(ks)) : 1;
             c->level_k6 = k ? std::max(1, atoi(k)) : 9; // 9 -> 56-row blocks: the halo re-reads cost 11 % instead of 19 % (32 rows); the step time is the same
             const bool fits = (p.width & 3) == 0 && (double)B * p.width * p.height * 3 < 4294967296.0 &&
-                              (double)B * g.slab < 4294967296.0 && (size_t)B * (p.width / 4) < (1u << 22) && p.height >= 8;
+                              (double)B * g.slab < 4294901760.0 /* below k_level.hip's kDropLane */ && (size_t)B * (p.width / 4) < (1u << 22) && p.height >= 8;
             int n_fused = fits ? 1 : 0;
             // levels l > 0 (resize + blur): the level must be on the 12-byte-window tables of k_resize_col
             while(n_fused >= 1 && n_fused < p.n_levels && c->rs_q[n_fused] != SIZE_MAX && g.lv[n_fused].h >= 8 &&

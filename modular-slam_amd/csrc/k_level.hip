@@ -40,6 +40,8 @@ __device__ __forceinline__ uint32_t lv_dot2u(uint32_t pair, uint32_t taps, uint3
     return __builtin_amdgcn_udot2(a, b, acc, false);
 }
 
+constexpr uint32_t kDropLane = 0xFFFFFFF0u; // vector offset of a lane whose buffer stores are to be dropped (host: batch slabs < 0xFFFF0000 bytes)
+
 // per-lane REFLECT_101 selectors for the window [x0-4, x0+8) held as (L, B, R) = (left neighbour, own, right neighbour)
 struct EdgeSel
 {
@@ -180,17 +182,16 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
     const EdgeSel e = edge_selectors(4 * q, a.W);
     const uint32_t src_v = (uint32_t)(f + a.frame0) * (uint32_t)(a.W * a.H * 3) + 12u * (uint32_t)q;
     // Every lane stores every row, unconditionally: the compiler can then count the stores in its vmcnt waits and the
-    // loads stay two rows ahead (a store that may or may not issue makes every counted wait stricter).  Halo lanes and
-    // rows outside the block write to the dump words: the 256 pad bytes that end the frame's slab (api.hip: g.slab).
-    // The store offsets advance by one row per row in vector registers (two fast adds per row); halo lanes advance by 0.
-    const uint32_t dump_v = (uint32_t)(f + a.frame0) * a.slab + a.dump_off + 4u * (uint32_t)lane;
-    const uint32_t pitch_v = productive ? (uint32_t)a.pitch : 0u;
+    // loads stay two rows ahead (a store that may or may not issue makes every counted wait stricter).  The stores are
+    // buffer stores: the lane's column offset rides in the vector operand, the wave-uniform row offset in the scalar one (no
+    // vector address arithmetic per row), and what must not be written is dropped by the buffer's range check — a halo lane
+    // carries an offset beyond the buffer (kDropLane), a halo row is stored against an empty buffer (0 records).  Neither
+    // reaches the cache.  (Round 3 first wrote those to dump words behind the slab: one more write request per store.)
     const uint32_t col_v = (uint32_t)(f + a.frame0) * a.slab + 4u * (uint32_t)q;
-    uint32_t raw_v = productive ? col_v + (uint32_t)(y0 - 3) * (uint32_t)a.pitch : dump_v;  // raw row of block row i = 0
-    uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.pitch : dump_v; // blurred row of block row i = 0 (used from i = 6 on)
-    if(TILED)
-        blur_v = productive ? (uint32_t)(f + a.frame0) * a.slab + tiled_off((unsigned)a.pitch, 4 * q, y0 - 6) : dump_v;
-    const uint32_t prod01 = productive ? 1u : 0u;
+    const uint32_t raw_v = productive ? col_v : kDropLane;
+    const uint32_t blur_v = !productive ? kDropLane : TILED ? (uint32_t)(f + a.frame0) * a.slab + tiled_off((unsigned)a.pitch, 4 * q, 0) : col_v;
+    const uint32_t n_rec = (uint32_t)(a.frame0 + a.n_frames) * a.slab;
+    const BufRsrc blur_rs = __builtin_amdgcn_make_buffer_rsrc(a.blur, 0, (int)n_rec, 0x00020000);
     const uint32_t row_bytes = (uint32_t)a.W * 3u;
 
     // buffer loads: the wave-uniform row offset rides in the scalar offset operand, the lane's offset in the vector one —
@@ -217,16 +218,13 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
         ring[(PH + 2) % 3] = load(min(i + 2, R + 5));
         const Bgr3 w = ring[PH % 3];
         const uint32_t g = lv_gray4(w.a, w.b, w.c);
-        if(SRAW)
-            *reinterpret_cast<uint32_t*>(a.pyr + (raw ? raw_v : dump_v)) = g; // rows 3 .. R+2 need no reflection
+        if(SRAW) // rows 3 .. R+2 need no reflection; a halo row is stored against an empty buffer
+            __builtin_amdgcn_raw_buffer_store_b32(g, __builtin_amdgcn_make_buffer_rsrc(a.pyr, 0, raw ? (int)n_rec : 0, 0x00020000),
+                                                  (int)raw_v, (y0 - 3 + i) * a.pitch, 0);
         const uint32_t o = blur_feed<PH, EMIT>(st, g, e, a.bk);
         if(EMIT)
-            *reinterpret_cast<uint32_t*>(a.blur + blur_v) = o;
-        raw_v += pitch_v;
-        if(TILED)
-            blur_v = __umul24(prod01, tiled_row_step((unsigned)a.pitch, y0 - 6 + i)) + blur_v;
-        else
-            blur_v += pitch_v;
+            __builtin_amdgcn_raw_buffer_store_b32(o, blur_rs, (int)blur_v,
+                                                  (int)(TILED ? tiled_off((unsigned)a.pitch, 0, y0 - 6 + i) : (unsigned)((y0 - 6 + i) * a.pitch)), 0);
     };
     using std::integral_constant;
 #define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
@@ -299,20 +297,24 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     const uint4 t0 = a.qt[3 * qx], t1 = a.qt[3 * qx + 1], t2 = a.qt[3 * qx + 2];
     const uint32_t sel[4] = {t0.z, t0.w, t1.x, t1.y}, coef[4] = {t1.z, t1.w, t2.x, t2.y};
     const uint32_t src_v = (uint32_t)(f + a.frame0) * a.slab + t0.x;
-    // unconditional stores, halo lanes / halo rows to the slab's dump words: see k_gray_blur
-    const uint32_t dump_v = (uint32_t)(f + a.frame0) * a.slab + a.dump_off + 4u * (uint32_t)lane;
-    const uint32_t pitch_v = productive ? (uint32_t)a.dpitch : 0u;
+    // unconditional buffer stores, halo lanes / halo rows dropped by the range check: see k_gray_blur
     const uint32_t col_v = (uint32_t)(f + a.frame0) * a.slab + (uint32_t)a.dst_off + 4u * (uint32_t)qx;
-    uint32_t raw_v = productive ? col_v + (uint32_t)(y0 - 3) * (uint32_t)a.dpitch : dump_v;
-    uint32_t blur_v = productive ? col_v + (uint32_t)(y0 - 6) * (uint32_t)a.dpitch : dump_v;
-    if(TILED) // (see k_gray_blur)
-        blur_v = productive ? (uint32_t)(f + a.frame0) * a.slab + (uint32_t)a.dst_off + tiled_off((unsigned)a.dpitch, 4 * qx, y0 - 6) : dump_v;
-    const uint32_t prod01 = productive ? 1u : 0u;
+    const uint32_t raw_v = productive ? col_v : kDropLane;
+    const uint32_t blur_v = !productive ? kDropLane
+                            : TILED   ? (uint32_t)(f + a.frame0) * a.slab + (uint32_t)a.dst_off + tiled_off((unsigned)a.dpitch, 4 * qx, 0)
+                                      : col_v;
+    const uint32_t n_rec = (uint32_t)(a.frame0 + a.n_frames) * a.slab;
+    const BufRsrc blur_rs = __builtin_amdgcn_make_buffer_rsrc(a.blur, 0, (int)n_rec, 0x00020000);
     const uint8_t* src_lv = a.pyr + a.src_off;
 
     const BufRsrc src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, -1, 0x00020000);
     auto load = [&](int sy) { // (buffer load: scalar row offset + vector lane offset, see k_gray_blur)
         const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(src_rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), 0);
+        return Raw3{v.x, v.y, v.z};
+    };
+    auto load_if = [&](int sy, bool need) {
+        const BufRsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, need ? -1 : 0, 0x00020000);
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), 0);
         return Raw3{v.x, v.y, v.z};
     };
     auto hinterp = [&](const Raw3& w) {
@@ -369,9 +371,13 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
         int sy0, sy1;
         rows_of(i, sy0, sy1);
         {
-            int ny0, ny1;
+            int ny0, ny1, py0, py1;
             rows_of(min(i + 2, R + 5), ny0, ny1);
-            RA[(PH + 2) % 3] = load(ny0);
+            rows_of(min(i + 1, R + 5), py0, py1);
+            // hA of row i + 2 is taken over from hB when its upper source row is the lower one of row i + 1 (the common step at
+            // scale factors below 2): that row's window is then never looked at — the load still issues (the compiler counts
+            // its vmcnt waits statically) but against an empty buffer, which returns zeros without touching the cache
+            RA[(PH + 2) % 3] = load_if(ny0, ny0 != py1);
             RB[(PH + 2) % 3] = load(ny1);
         }
         // bring (hA, hB) to (sy0, sy1).  All conditions are wave-uniform; the empty asm statements keep the compiler from
@@ -436,16 +442,13 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
             asm volatile("");
             g = blend(hB, hB);
         }
-        if(SRAW)
-            *reinterpret_cast<uint32_t*>(a.pyr + (raw ? raw_v : dump_v)) = g; // rows 3 .. R+2 need no reflection
+        if(SRAW) // rows 3 .. R+2 need no reflection; a halo row is stored against an empty buffer (see k_gray_blur)
+            __builtin_amdgcn_raw_buffer_store_b32(g, __builtin_amdgcn_make_buffer_rsrc(a.pyr, 0, raw ? (int)n_rec : 0, 0x00020000),
+                                                  (int)raw_v, (y0 - 3 + i) * a.dpitch, 0);
         const uint32_t o = blur_feed<PH, EMIT>(st, g, e, a.bk);
         if(EMIT)
-            *reinterpret_cast<uint32_t*>(a.blur + blur_v) = o;
-        raw_v += pitch_v;
-        if(TILED)
-            blur_v = __umul24(prod01, tiled_row_step((unsigned)a.dpitch, y0 - 6 + i)) + blur_v;
-        else
-            blur_v += pitch_v;
+            __builtin_amdgcn_raw_buffer_store_b32(o, blur_rs, (int)blur_v,
+                                                  (int)(TILED ? tiled_off((unsigned)a.dpitch, 0, y0 - 6 + i) : (unsigned)((y0 - 6 + i) * a.dpitch)), 0);
     };
     using std::integral_constant;
 #define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
