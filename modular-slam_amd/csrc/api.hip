@@ -865,6 +865,7 @@ static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, co
     ra.exact = exact;
     ra.dump_off = g.slab - 256;
     ra.blur_tiled = g.blur_tiled;
+    ra.always_load = nf < 8 ? 1 : 0;
     ra.bk = make_blur_k();
     launch_resize_blur(ra, cs);
 }

@@ -176,6 +176,7 @@ struct ResizeBlurArgs
     unsigned dump_off; // offset of the 256 pad bytes that end every frame's slab
     int waves_per_xcd; // filled in by the launcher
     int blur_tiled;    // Geometry::blur_tiled
+    int always_load;   // 1: load the upper source-row window even where the walk does not look at it (latency-bound launches)
     BlurK bk;
 };
 void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s);

@@ -355,30 +355,32 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     // both source rows of every destination row are requested two rows ahead, unconditionally (static 3-deep ring: the
     // compiler can count its vmcnt waits); whether a row is interpolated again or taken over from hB is decided at use
     Raw3 RA[3], RB[3];
-#pragma unroll
-    for(int i = 0; i < 2; ++i)
-    {
-        int sy0, sy1;
-        rows_of(i, sy0, sy1);
-        RA[i] = load(sy0);
-        RB[i] = load(sy1);
-    }
+    // the source rows of block rows i and i + 1 are carried from the iterations that requested them (one table lookup per row)
+    int c0_y0, c0_y1, c1_y0, c1_y1;
+    rows_of(0, c0_y0, c0_y1);
+    rows_of(1, c1_y0, c1_y1);
+    RA[0] = load(c0_y0);
+    RB[0] = load(c0_y1);
+    RA[1] = load(c1_y0);
+    RB[1] = load(c1_y1);
 
     auto row = [&](auto ph, auto emit, auto sraw, int i, bool raw) {
         constexpr int PH = decltype(ph)::value;
         constexpr bool EMIT = decltype(emit)::value;
         constexpr bool SRAW = decltype(sraw)::value; // false for block rows 0 .. 2: no raw store is emitted at all
-        int sy0, sy1;
-        rows_of(i, sy0, sy1);
+        const int sy0 = c0_y0, sy1 = c0_y1;
         {
-            int ny0, ny1, py0, py1;
+            int ny0, ny1;
             rows_of(min(i + 2, R + 5), ny0, ny1);
-            rows_of(min(i + 1, R + 5), py0, py1);
             // hA of row i + 2 is taken over from hB when its upper source row is the lower one of row i + 1 (the common step at
             // scale factors below 2): that row's window is then never looked at — the load still issues (the compiler counts
             // its vmcnt waits statically) but against an empty buffer, which returns zeros without touching the cache
-            RA[(PH + 2) % 3] = load_if(ny0, ny0 != py1);
+            // (0.72 -> 0.68 ms per 1000 frames; an empty-buffer load takes longer to return than a cache hit, so the handful-of-
+            // frames launches, which run at the latency of one wave's walk, keep the real load: always_load)
+            RA[(PH + 2) % 3] = load_if(ny0, ny0 != c1_y1 || a.always_load);
             RB[(PH + 2) % 3] = load(ny1);
+            c0_y0 = c1_y0, c0_y1 = c1_y1;
+            c1_y0 = ny0, c1_y1 = ny1;
         }
         // bring (hA, hB) to (sy0, sy1).  All conditions are wave-uniform; the empty asm statements keep the compiler from
         // turning the branches into speculated work + selects.

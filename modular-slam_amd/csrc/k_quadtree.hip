@@ -555,7 +555,10 @@ void launch_quadtree(const Geometry& g, const QuadArgs& a, int frame0, int n_fra
         if(g.lv[l].w * g.lv[l].h > kBigMinPixels)
             big_levels |= 1u << l;
     // MSLAM_HIP_QUAD_CLASSES: bit 0 = small instance, bit 1 = mid instance (default both; 0 = the large instance alone)
-    static const unsigned classes = [] { const char* e = getenv("MSLAM_HIP_QUAD_CLASSES"); return e ? (unsigned)atoi(e) & 3u : 3u; }();
+    static const unsigned classes_env = [] { const char* e = getenv("MSLAM_HIP_QUAD_CLASSES"); return e ? (unsigned)atoi(e) & 3u : 3u; }();
+    // a handful of frames (the synchronous single-frame call): one launch — there is no occupancy to gain, and every launch
+    // is a few microseconds of the call's latency
+    const unsigned classes = n_frames < 8 ? 0u : classes_env;
     const unsigned bl = big_levels | (classes << 30);
     hipLaunchKernelGGL((k_quadtree<kLdsKp, QT, 2>), grid, dim3(QT), 0, s, gg, a, bl);
     if(classes & 2u)
