@@ -102,7 +102,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         //      Pixels are widened to u16 pairs and compared with packed 16-bit subtracts (sign bit = result).
         {
             const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
-            const int i4 = lane & 15, sub = lane >> 4;
+            // lane = (row sub, column group i4) of a step.  A full cell has 16 column groups (64 tested columns) and a wave
+            // step covers 4 rows; the narrow cells that end a level's cell rows (and the short ones that end its cell columns)
+            // use fewer groups per row and more rows per step — lg = log2(groups per row) — and only as many steps as they
+            // have rows: 8 % of the steps of a 640x480 pyramid are saved.  (The order of the list is irrelevant: it is a
+            // work queue, the output order comes from the bitmap.)
+            const int ngrp = (cw - 6 + 3) >> 2;                                             // column groups that hold a tested column
+            const int lg = ngrp > 8 ? 4 : ngrp > 4 ? 3 : ngrp > 2 ? 2 : ngrp > 1 ? 1 : 0; // (wave-uniform)
+            const int i4 = lane & ((1 << lg) - 1), sub = lane >> lg;
+            const int rps = 64 >> lg;                                                     // rows per wave step
+            const int n_steps = (ch - 6 + rps - 1) >> (6 - lg);                            // row steps of the cell, dealt to the waves round-robin
             const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
             // which of this lane's four columns 3+4i .. 6+4i are tested (x < cw - 3)
             const int xl = 3 + 4 * i4;
@@ -110,9 +119,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const uint32_t colmask = (xl < cw - 3 ? 0x80u : 0u) | (xl + 1 < cw - 3 ? 0x8000u : 0u) |
                                      (xl + 2 < cw - 3 ? 0x800000u : 0u) | (xl + 3 < cw - 3 ? 0x80000000u : 0u);
 #pragma unroll 1
-            for(int it = 0; it < 4; ++it)
+            for(int st = __builtin_amdgcn_readfirstlane(wave); st < n_steps; st += 4)
             {
-                const int y = 3 + wave * 16 + it * 4 + sub;
+                const int y = 3 + st * rps + sub;
                 uint32_t keep = 0;
                 if(colmask != 0 && y < ch - 3)
                 {
