@@ -78,6 +78,9 @@ __device__ __forceinline__ float util_sin(float v)
 constexpr int kPatchR = 18;               // the rotated pattern reaches |18| (its radius is 18.38; the reference keeps a 19-px border)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
 constexpr int kPatchDw = 12;              // 48-byte rows: 37 needed bytes from a 16-byte aligned start, or from 12 bytes past one
+#ifndef MSLAM_DISC_DW
+#define MSLAM_DISC_DW 16
+#endif
 constexpr int kPatchDwT = 16;             // tiled blurred plane (below): up to four aligned 16-byte chunks per row
 constexpr int kPatchBufsT = 4;            // ... and a 4-slot ring (37 x 64 bytes per slot: 37.9 KB per workgroup, 4 workgroups per CU)
 constexpr int kPatchBufs = 5;            // LDS patch ring per wave: one being sampled, four in flight (3 / 4 / 5 slots of 1776 bytes: 0.505 / 0.493 / 0.486 ms per 500 frames; 35.5 KB per workgroup = 4 workgroups per CU: with 5 (4 slots) the frames in flight per XCD outgrow its L2 and the memory-side reads rise from 1.9 to 2.2 MB per frame)
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
 {
     constexpr int kBufs = TILED ? kPatchBufsT : kPatchBufs;
     constexpr int kSlotDw = kPatchRows * (TILED ? kPatchDwT : kPatchDw);
+    constexpr int kDiscDw = TILED ? MSLAM_DISC_DW : 12; // LDS row pitch of the raw disc window in dwords
     __shared__ __attribute__((aligned(16))) uint32_t patch[4][kBufs][kSlotDw];
 
     // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, so all kBlocksPerFrame
@@ -275,7 +279,15 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 for(int q = 0; q < 2; ++q)
                 {
                     const uint32_t t = (uint32_t)lane + 64u * q;
-                    if(t < 93u)
+                    if(kDiscDw == 16)
+                    {
+                        // four lanes per row (the fourth idle): every quad of lanes asks for ONE row, i.e. one cache line
+                        if(t < 124u && (t & 3u) != 3u)
+                            __builtin_amdgcn_global_load_lds(
+                                (const __attribute__((address_space(1))) void*)(src + __umul24(t >> 2, pitch) + 16u * (t & 3u)),
+                                (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                    }
+                    else if(t < 93u)
                     {
                         const uint32_t row = (t * 21846u) >> 16; // t / 3
                         __builtin_amdgcn_global_load_lds(
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                     uint32_t x = 0x80808080u;
                     if(t < 31 * 8)
                     {
-                        const uint32_t* e = d + (t >> 3) * 12 + (t & 7);
+                        const uint32_t* e = d + (t >> 3) * kDiscDw + (t & 7);
                         x = __builtin_amdgcn_alignbyte(e[1], e[0], sh & 3);
                     }
                     x ^= 0x80808080u;
