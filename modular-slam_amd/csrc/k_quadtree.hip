@@ -418,8 +418,9 @@ __device__ __forceinline__ int quad_class(uint32_t N, int n_cells, unsigned clas
         return 1;
     return 2;
 }
+// (waves per SIMD: the small and mid instances must fit 8 — 8 x 4 resp. 4 x 8 waves per CU —, i.e. 64 registers)
 template <int KP, int NT, int CLS>
-__global__ __launch_bounds__(NT) void k_quadtree(Geometry g, QuadArgs a, unsigned big_levels)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(CLS == 2 ? 4 : 8))) void k_quadtree(Geometry g, QuadArgs a, unsigned big_levels)
 {
     __shared__ Scan scan, scan2;
     __shared__ uint32_t l_cand[KP];
