@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
         }
 
         // ---- C. descriptors
+        uint32_t desc_lo = 0, desc_hi = 0;
         {
             // (the patches were requested by dma_patch above: 37 rows x 48 bytes each, lane-linear in LDS)
             auto describe = [&](int k, int buf) {
@@ -486,13 +487,14 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                     asm volatile("");
                     sample(std::false_type{});
                 }
-                if(lane < 4)
+                // the batch's descriptors are collected in lanes (4 k + t holds dword pair t of keypoint k) and stored once per batch — one store instruction instead of sixteen on the
+                // memory pipeline the window fetches are queued on
+#pragma unroll
+                for(int t = 0; t < 4; ++t)
                 {
-                    unsigned long long w = bits[0];
-                    w = lane == 1 ? bits[1] : w;
-                    w = lane == 2 ? bits[2] : w;
-                    w = lane == 3 ? bits[3] : w;
-                    reinterpret_cast<unsigned long long*>(a.desc + (frame * (size_t)a.max_kp + base + k * kStr) * 32)[lane] = w;
+                    const bool mine = lane == 4 * k + t;
+                    desc_lo = mine ? (uint32_t)bits[t] : desc_lo;
+                    desc_hi = mine ? (uint32_t)(bits[t] >> 32) : desc_hi;
                 }
             };
             static_assert(kBufs >= 2 && kBufs <= 5, "the vmcnt immediates of phases A and C cover up to four younger windows");
@@ -523,6 +525,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 __builtin_amdgcn_wave_barrier(); // the gathers are done before the slot is refilled
             }
         }
+        if(lane < 4 * n_here)
+            reinterpret_cast<uint2*>(a.desc + (frame * (size_t)a.max_kp + base + (lane >> 2) * kStr) * 32)[lane & 3] = make_uint2(desc_lo, desc_hi);
         if(lane < n_here)
         {
             const size_t o = frame * (size_t)a.max_kp + base + lane * kStr;
