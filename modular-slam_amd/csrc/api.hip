@@ -863,7 +863,6 @@ static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, co
     }
     ra.need_mask = c->rs_need[l];
     ra.exact = exact;
-    ra.dump_off = g.slab - 256;
     ra.blur_tiled = g.blur_tiled;
     ra.always_load = nf < 8 ? 1 : 0;
     ra.bk = make_blur_k();
@@ -901,7 +900,6 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 ga.bgr = d_bgr;
                 ga.pyr = c->d_pyr;  // (level 0 starts the slab)
                 ga.blur = c->d_blur;
-                ga.dump_off = g.slab - 256;
                 ga.W = g.W, ga.H = g.H, ga.pitch = g.lv[0].pitch;
                 ga.slab = g.slab;
                 ga.n_frames = nf, ga.frame0 = f0;

@@ -55,12 +55,6 @@ __host__ __device__ __forceinline__ unsigned tiled_off(unsigned pitch, int x, in
     return (unsigned)(y >> kTileHLog) * (pitch * (unsigned)kTileH) + (unsigned)(x >> kTileWLog) * 128u +
            (unsigned)(y & (kTileH - 1)) * (unsigned)kTileW + (unsigned)(x & (kTileW - 1));
 }
-// byte step from row y to row y + 1 of the same column
-__host__ __device__ __forceinline__ unsigned tiled_row_step(unsigned pitch, int y)
-{
-    return ((y + 1) & (kTileH - 1)) != 0 ? (unsigned)kTileW : pitch * (unsigned)kTileH - (unsigned)((kTileH - 1) * kTileW);
-}
-
 // FAST cell: a sub-image [x0, x0+cw) x [y0, y0+ch) of one level (:880-905).
 struct CellDesc
 {
@@ -151,7 +145,6 @@ struct GrayBlurArgs
     int quads;          // W / 4
     float inv_quads;
     int k6;             // rows per block = 6 k6 + 2
-    unsigned dump_off;  // offset (from the slab's first byte) of the 256 pad bytes that end every frame's slab
     int waves_per_xcd;  // filled in by the launcher
     int blur_tiled;     // Geometry::blur_tiled
     BlurK bk;
@@ -173,7 +166,6 @@ struct ResizeBlurArgs
     int k6;        // rows per block = 6 k6 + 2 (<= 58: the block's row table lives in lane registers)
     int need_mask; // bit k: pixel k of some quad takes its pair from dwords (1,2)
     int exact;     // 0: INTER_LINEAR, 1: INTER_LINEAR_EXACT
-    unsigned dump_off; // offset of the 256 pad bytes that end every frame's slab
     int waves_per_xcd; // filled in by the launcher
     int blur_tiled;    // Geometry::blur_tiled
     int always_load;   // 1: load the upper source-row window even where the walk does not look at it (latency-bound launches)

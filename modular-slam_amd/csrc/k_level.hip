@@ -158,9 +158,8 @@ struct Bgr3
 
 // ---- level 0: gray + blur --------------------------------------------------------------------------------------------
 // TILED: the blurred plane is written in kTileW x kTileH pixel tiles (common.hpp: tiled_off; k_describe's patches then
-// touch fewer lines).  A lane's dword keeps its place inside the tile row; going down one row is +kTileW bytes, or on to
-// the next tile row after a tile's last row — a wave-uniform step, applied to productive lanes only (halo lanes stay on
-// their dump word).
+// touch fewer lines).  A lane's dword keeps its place inside the tile row (its vector offset); the row's offset inside the
+// plane — tiled_off(pitch, 0, y) — is wave-uniform and rides in the store's scalar offset.
 template <bool TILED>
 __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
 {
