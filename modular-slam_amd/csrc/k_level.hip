@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
         const Bgr3 w = ring[PH % 3];
         const uint32_t g = lv_gray4(w.a, w.b, w.c);
         if(SRAW) // rows 3 .. R+2 need no reflection; a halo row is stored against an empty buffer
-            __builtin_amdgcn_raw_buffer_store_b32(g, __builtin_amdgcn_make_buffer_rsrc(a.pyr, 0, raw ? (int)n_rec : 0, 0x00020000),
+            __builtin_amdgcn_raw_buffer_store_b32(g, __builtin_amdgcn_make_buffer_rsrc(a.pyr, 0, __builtin_amdgcn_readfirstlane(raw ? (int)n_rec : 0), 0x00020000),
                                                   (int)raw_v, (y0 - 3 + i) * a.pitch, 0);
         const uint32_t o = blur_feed<PH, EMIT>(st, g, e, a.bk);
         if(EMIT)
@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
         return Raw3{v.x, v.y, v.z};
     };
     auto load_if = [&](int sy, bool need) {
-        const BufRsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, need ? -1 : 0, 0x00020000);
+        // (readfirstlane: the record count must be a scalar register for the compiler, else it wraps the load in a waterfall loop)
+        const BufRsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, __builtin_amdgcn_readfirstlane(need ? -1 : 0), 0x00020000);
         const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), 0);
         return Raw3{v.x, v.y, v.z};
     };
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
             g = blend(hB, hB);
         }
         if(SRAW) // rows 3 .. R+2 need no reflection; a halo row is stored against an empty buffer (see k_gray_blur)
-            __builtin_amdgcn_raw_buffer_store_b32(g, __builtin_amdgcn_make_buffer_rsrc(a.pyr, 0, raw ? (int)n_rec : 0, 0x00020000),
+            __builtin_amdgcn_raw_buffer_store_b32(g, __builtin_amdgcn_make_buffer_rsrc(a.pyr, 0, __builtin_amdgcn_readfirstlane(raw ? (int)n_rec : 0), 0x00020000),
                                                   (int)raw_v, (y0 - 3 + i) * a.dpitch, 0);
         const uint32_t o = blur_feed<PH, EMIT>(st, g, e, a.bk);
         if(EMIT)
