@@ -96,7 +96,8 @@ __device__ __forceinline__ uint32_t blur_feed(BlurRing& st, uint32_t B, const Ed
     const uint32_t B2 = __builtin_amdgcn_perm(B, L, e.selB);
     const uint32_t T = __builtin_amdgcn_perm(B, L, e.selT);
     const uint32_t U = __builtin_amdgcn_perm(R, B, e.selU);
-    const uint32_t C2 = (T & e.maskT) | (U & ~e.maskT);
+    uint32_t C2; // (T & maskT) | (U & ~maskT) as one instruction (the compiler builds it from two)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(C2) : "v"(e.maskT), "v"(T), "v"(U));
     uint32_t hv[4];
     hv[0] = __builtin_amdgcn_udot4(A2, k.ta[0], __builtin_amdgcn_udot4(B2, k.tb[0], 0u, false), false);
     hv[1] = __builtin_amdgcn_udot4(A2, k.ta[1], __builtin_amdgcn_udot4(B2, k.tb[1], __builtin_amdgcn_udot4(C2, k.tc[1], 0u, false), false), false);
@@ -428,8 +429,11 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
                 uint32_t v[4];
 #pragma unroll
                 for(int k = 0; k < 4; ++k)
-                    v[k] = (__umulhi(h0.h[k], b0s) + __umulhi(h1.h[k], b1s) + 2u) >> 2; // <= 255
-                r = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0400u) | __builtin_amdgcn_perm(v[3], v[2], 0x04000C0Cu);
+                    v[k] = __umulhi(h0.h[k], b0s) + __umulhi(h1.h[k], b1s) + 2u; // <= 1022; the pixel is v >> 2
+                // two sums per register, ONE shift per pair (a pair's low bits fall into bits 14, 15 of the other's field,
+                // which no byte of the result is taken from), one byte gather
+                const uint32_t p01 = (v[0] | (v[1] << 16)) >> 2, p23 = (v[2] | (v[3] << 16)) >> 2;
+                r = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
             }
             return r;
         };
