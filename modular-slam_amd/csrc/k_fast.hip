@@ -139,7 +139,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     {
                         const uint32_t sel = h == 0 ? 0x0c010c00u : 0x0c030c02u; // bytes (0,1) or (2,3) as u16 lanes
                         typedef short s16x2 __attribute__((ext_vector_type(2)));
-                        auto w = [&](uint32_t v) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, v, sel)); };
+                        // (the selector as a scalar operand: as a vector constant it holds a register the kernel, capped at 64, spills for)
+                        auto w = [&](uint32_t v) {
+                            uint32_t d;
+                            asm("v_perm_b32 %0, 0, %1, %2" : "=v"(d) : "v"(v), "s"(sel));
+                            return __builtin_bit_cast(s16x2, d);
+                        };
                         const s16x2 t2 = __builtin_bit_cast(s16x2, thr2);
                         const s16x2 cc = w(C), hi = cc + t2, lo = cc - t2;
                         const s16x2 p0 = w(D), p4 = w(Rt), p8 = w(U), p12 = w(Lf);
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     {
                         const int m = __builtin_amdgcn_sbfe((int)keep, 8 * k + 7, 1); // -1 when kept
                         uint32_t slot2;
-                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(slot2) : "v"(m), "v"(pos2), "v"(dump2));
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(slot2) : "v"(m), "v"(pos2), "s"(dump2));
                         *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(cand) + slot2) = (uint16_t)(yx + k);
                         pos2 = (uint32_t)__mul24(m, -2) + pos2;
                     }
