@@ -373,6 +373,43 @@ def test_pyramid_and_blur_forms(pkg, orc, bundled_frames, synth_frames, monkeypa
         c.close()
 
 
+@pytest.mark.parametrize("tiled", ["1", "0"])
+def test_blurred_slab_tiled_and_in_rows(pkg, orc, bundled_frames, synth_frames, monkeypatch, tiled):
+    """the blurred slab in 64 x 2 pixel tiles (the default when every level is fused; k_describe<true>) and in rows
+    (MSLAM_HIP_TILED_BLUR=0; k_describe<false>): blurred planes as mslam_hip_debug_read returns them (it puts tiles back into
+    rows), detections of single frames and of a batch, sizes whose row pitch is and is not a multiple of 64"""
+    import torch
+    import synth
+    monkeypatch.setenv("MSLAM_HIP_TILED_BLUR", tiled)
+    p = orc.params()
+    for W, H, frame in ((640, 480, bundled_frames[0]), (404, 300, None), (1000, 270, None)):
+        if frame is None:
+            frame = synth.make_stream(1, W, H, seed=W + 1)[0]
+        c = pkg.Context(width=W, height=H, max_batch=9, max_keypoints=16384, max_candidates=65536)
+        got, ref = c.detect(frame), orc.detect(frame, p)
+        pyr = orc.pyramid(orc.gray(frame), p)
+        for l in range(8):
+            assert np.array_equal(c.debug_image(pkg.DBG_BLURRED, 0, l), orc.gaussian_blur7(pyr[l])), "blur %d" % l
+        assert_same_detection(got, ref)
+        if W == 640:
+            batch = np.stack([synth_frames[i % 6] for i in range(9)])
+            c.detect_batch_dev(torch.from_numpy(batch).cuda().data_ptr(), 9)
+            c.sync()
+            for f in (0, 8):
+                pyr = orc.pyramid(orc.gray(batch[f]), p)
+                for l in (0, 3, 7):
+                    assert np.array_equal(c.debug_image(pkg.DBG_BLURRED, f, l), orc.gaussian_blur7(pyr[l])), "blur %d %d" % (f, l)
+            v, K = c.batch_view(), 16384
+            cnt = pkg.read_device(c, v.count, (9,), np.int32)
+            desc = pkg.read_device(c, v.desc, (9, K, 32), np.uint8)
+            ang = pkg.read_device(c, v.angle, (9, K), np.float32)
+            for f in (0, 5, 8):
+                r = orc.detect(batch[f], p)
+                assert cnt[f] == len(r["xy"])
+                assert np.array_equal(desc[f, :cnt[f]], r["desc"]) and np.array_equal(ang[f, :cnt[f]], r["angle"])
+        c.close()
+
+
 def test_sparse_corners_use_fallback_threshold(pkg, orc):
     """cells without any threshold-20 corner must fall back to threshold 7 (:922-926): a dark frame with a few
     faint squares has corners only at the low threshold."""
