@@ -108,7 +108,15 @@ void bow_destroy(BowState* b)
 
 // ---- kernels ------------------------------------------------------------------------------------------
 
-// 16 lanes walk one descriptor down the tree; lane c scores child c of the current node.
+// 16 lanes walk kBowDepth descriptors down the tree side by side; lane c scores child c of each one's current node.
+// A level is one dependent memory round trip (from the fifth level on the nodes of a 10^6-word vocabulary come from the
+// memory side: 1-2 us), so what sets the kernel's time is how many descents are in flight: with one per lane group it
+// ran at that latency (0.40 ms per 1000 frames at full occupancy); kBowDepth of them issue their loads together.
+// (2: 0.69 -> 0.48 ms in place, cfg3 step -0.8 %; 4 and 8 cost more in registers / occupancy than they add: 0.82 / 1.77 ms.)
+#ifndef MSLAM_BOW_DEPTH
+#define MSLAM_BOW_DEPTH 2
+#endif
+constexpr int kBowDepth = MSLAM_BOW_DEPTH;
 __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t* __restrict__ desc, long long desc_stride,
                                                      const int32_t* __restrict__ counts, int n_fixed, int cap,
                                                      const uint4* __restrict__ tdesc, const uint32_t* __restrict__ first,
@@ -119,54 +127,98 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t* __restrict__
     const int frame = blockIdx.y;
     const int n = min(counts ? counts[frame] : n_fixed, cap);
     const int sub = threadIdx.x & (kBowGroup - 1);
-    const int i = (blockIdx.x * 256 + threadIdx.x) / kBowGroup;
-    if(i >= n)
+    const int i0 = ((blockIdx.x * 256 + threadIdx.x) / kBowGroup) * kBowDepth;
+    if(i0 >= n)
         return; // whole 16-lane group leaves together
-    const uint4* q = reinterpret_cast<const uint4*>(desc + (long long)frame * desc_stride + (size_t)i * 32);
-    const uint4 qa = q[0], qb = q[1];
+    uint4 qa[kBowDepth], qb[kBowDepth];
+    uint32_t node[kBowDepth], fc[kBowDepth], nc[kBowDepth];
+    const uint32_t fc0 = first[0], nc0 = nchild[0];
+#pragma unroll
+    for(int d = 0; d < kBowDepth; ++d)
+    {
+        const int i = min(i0 + d, n - 1); // (a group's surplus slots repeat its last descriptor; nothing is stored for them)
+        const uint4* q = reinterpret_cast<const uint4*>(desc + (long long)frame * desc_stride + (size_t)i * 32);
+        qa[d] = q[0], qb[d] = q[1];
+        node[d] = 0, fc[d] = fc0, nc[d] = nc0;
+    }
     // One dependent memory round trip per tree level: lane c fetches child c's descriptor AND child c's own
     // (first child, child count) together; after the argmin the winner's pair comes from the winning lane by
     // shuffle instead of from memory (first[] -> children -> nchild[] used to be three round trips per level).
-    uint32_t node = 0;
-    uint32_t fc = first[0], nc = nchild[0];
-    while(nc != 0)
+    for(;;)
     {
-        uint32_t best = 0xFFFFFFFFu; // (distance << 16) | child index: min == first child with the least distance
-        uint32_t best_fc = 0, best_nc = 0;
-        for(uint32_t c0 = 0; c0 < nc; c0 += kBowGroup)
+        bool any = false;
+#pragma unroll
+        for(int d = 0; d < kBowDepth; ++d)
+            any = any || nc[d] != 0; // (uniform over the group)
+        if(!any)
+            break;
+        uint32_t best[kBowDepth], best_fc[kBowDepth], best_nc[kBowDepth];
+        uint4 ta[kBowDepth], tb[kBowDepth];
+        uint32_t cf[kBowDepth], cn[kBowDepth];
+        // every descent's loads first ...
+#pragma unroll
+        for(int d = 0; d < kBowDepth; ++d)
         {
-            const uint32_t c = c0 + sub;
-            if(c < nc)
+            best[d] = 0xFFFFFFFFu; // (distance << 16) | child index: min == first child with the least distance
+            best_fc[d] = 0, best_nc[d] = 0;
+            ta[d] = tb[d] = make_uint4(0, 0, 0, 0);
+            cf[d] = cn[d] = 0;
+            if((uint32_t)sub < nc[d])
             {
-                const uint4* t = tdesc + (size_t)(fc + c) * 2;
-                const uint4 ta = t[0], tb = t[1];
-                const uint32_t cf = first[fc + c], cn = nchild[fc + c];
-                const uint32_t d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-                                   __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-                const uint32_t key = (d << 16) | c;
-                if(key < best)
-                {
-                    best = key;
-                    best_fc = cf;
-                    best_nc = cn;
-                }
+                const uint4* t = tdesc + (size_t)(fc[d] + sub) * 2;
+                ta[d] = t[0], tb[d] = t[1];
+                cf[d] = first[fc[d] + sub], cn[d] = nchild[fc[d] + sub];
             }
         }
-        uint32_t all = best;
+        // ... then their scores (nodes with more than 16 children take further rounds, one descent at a time)
 #pragma unroll
-        for(int o = kBowGroup / 2; o > 0; o >>= 1)
-            all = min(all, (uint32_t)__shfl_xor((int)all, o, kBowGroup));
-        // keys are unique (they carry the child index): exactly one lane of the group holds the winner
-        const int src = (int)((all & 0xFFFFu) % kBowGroup); // the lane that scored child (all & 0xFFFF)
-        node = fc + (all & 0xFFFFu);
-        fc = (uint32_t)__shfl((int)best_fc, src, kBowGroup);
-        nc = (uint32_t)__shfl((int)best_nc, src, kBowGroup);
+        for(int d = 0; d < kBowDepth; ++d)
+        {
+            if(nc[d] == 0)
+                continue;
+            for(uint32_t c0 = 0; c0 < nc[d]; c0 += kBowGroup)
+            {
+                const uint32_t c = c0 + sub;
+                if(c < nc[d])
+                {
+                    if(c0 != 0)
+                    {
+                        const uint4* t = tdesc + (size_t)(fc[d] + c) * 2;
+                        ta[d] = t[0], tb[d] = t[1];
+                        cf[d] = first[fc[d] + c], cn[d] = nchild[fc[d] + c];
+                    }
+                    const uint32_t dist = __popc(qa[d].x ^ ta[d].x) + __popc(qa[d].y ^ ta[d].y) + __popc(qa[d].z ^ ta[d].z) +
+                                          __popc(qa[d].w ^ ta[d].w) + __popc(qb[d].x ^ tb[d].x) + __popc(qb[d].y ^ tb[d].y) +
+                                          __popc(qb[d].z ^ tb[d].z) + __popc(qb[d].w ^ tb[d].w);
+                    const uint32_t key = (dist << 16) | c;
+                    if(key < best[d])
+                    {
+                        best[d] = key;
+                        best_fc[d] = cf[d];
+                        best_nc[d] = cn[d];
+                    }
+                }
+            }
+            uint32_t all = best[d];
+#pragma unroll
+            for(int o = kBowGroup / 2; o > 0; o >>= 1)
+                all = min(all, (uint32_t)__shfl_xor((int)all, o, kBowGroup));
+            // keys are unique (they carry the child index): exactly one lane of the group holds the winner
+            const int src = (int)((all & 0xFFFFu) % kBowGroup); // the lane that scored child (all & 0xFFFF)
+            node[d] = fc[d] + (all & 0xFFFFu);
+            fc[d] = (uint32_t)__shfl((int)best_fc[d], src, kBowGroup);
+            nc[d] = (uint32_t)__shfl((int)best_nc[d], src, kBowGroup);
+        }
     }
-    if(sub == 0)
+    if(sub < kBowDepth && i0 + sub < n)
     {
-        const size_t o = (size_t)frame * cap + i;
-        out_word[o] = word[node];
-        out_weight[o] = weight[node];
+        uint32_t nd = node[0];
+#pragma unroll
+        for(int d = 1; d < kBowDepth; ++d)
+            nd = sub == d ? node[d] : nd;
+        const size_t o = (size_t)frame * cap + i0 + sub;
+        out_word[o] = word[nd];
+        out_weight[o] = weight[nd];
     }
 }
 
@@ -1179,8 +1231,8 @@ static int bow_transform_dev(mslam_hip_ctx* c, const uint8_t* d_desc, long long 
     else
     {
         StageScope t(c, "bow_descend");
-        const int groups_per_block = 256 / kBowGroup;
-        dim3 grid((cap + groups_per_block - 1) / groups_per_block, n_frames);
+        const int per_block = (256 / kBowGroup) * kBowDepth; // descriptors per workgroup
+        dim3 grid((cap + per_block - 1) / per_block, n_frames);
         hipLaunchKernelGGL(k_bow_descend, grid, dim3(256), 0, s, d_desc, stride, d_counts, n_fixed, cap, b->d_desc,
                            b->d_first, b->d_nchild, b->d_word, b->d_weight, b->d_fword + (size_t)slot0 * cap,
                            b->d_fweight + (size_t)slot0 * cap);
