@@ -120,7 +120,8 @@ void launch_resize_exact(const ExactResizeArgs& a, int n_frames, hipStream_t s)
 // S = max over the 16 arcs of 9 of min(d) resp. min(-d), minus 1; corner iff S >= thr).  Keypoints inside the
 // runByImageBorder(edge) rectangle are appended to the level's list (one global atomic per wave); the list is put into
 // FAST's raster order by k_cv_select.
-constexpr int kSP = 72; // LDS tile pitch = tile width 64 + 2 * (3 + 1)
+constexpr int kSP = 96; // LDS tile pitch: six 16-byte LDS-DMA chunks from column X0 - 16 on (a 16-byte boundary); the 72 pixels the
+constexpr int kSX = 12; // tile needs (X0 - 4 ...) start at byte kSX of a row
 constexpr int kSc = 68; // score-map pitch (66 used)
 
 __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ pyr, Geometry g, int level, int tiles_x,
@@ -146,21 +147,24 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
     const uint8_t* src = pyr + frame * g.slab + lv.offset;
     const int tid = threadIdx.x, lane = tid & 63;
 
-    for(int i = tid; i < 72 * 18; i += 256) // 72 rows x 18 dwords (4 pixels each)
+    // stage the 72 rows by LDS-DMA (as k_fast_cells: no registers, no vector instructions for the copy): chunk t = (row
+    // t / 6, chunk t % 6) lands at tile + 16 t.  Rows outside the level repeat its first / last row, chunks outside the
+    // row pitch are skipped: what they would hold is only ever read by pixels that are not tested.
+#pragma unroll
+    for(int p = 0; p < 2; ++p)
     {
-        const int r = i / 18, q = i - r * 18;
-        const int y = min(max(Y0 - 4 + r, 0), h - 1), x = X0 - 4 + 4 * q;
-        uint32_t v;
-        if(x >= 0 && x + 3 < pitch) // X0 and the pitch are multiples of 4: aligned dword inside the row
-            v = *reinterpret_cast<const uint32_t*>(src + (size_t)y * pitch + x);
-        else
-            v = 0; // outside the level: only ever read by pixels that are not tested
-        reinterpret_cast<uint32_t*>(tile)[r * (kSP / 4) + q] = v;
+        const int t = p * 256 + tid;
+        const int r = (t * 10923) >> 16, c = t - r * 6; // t / 6 for t < 32768
+        const int y = min(max(Y0 - 4 + r, 0), h - 1), x = X0 - 16 + 16 * c;
+        if(t < 72 * 6 && x >= 0 && x < pitch)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)y * pitch + x),
+                                             (__attribute__((address_space(3))) void*)&tile[(p * 256 + (tid & ~63)) * 16], 16, 0, 0);
     }
     for(int i = tid; i < 66 * kSc / 4; i += 256)
         reinterpret_cast<uint32_t*>(sc)[i] = 0;
     if(tid == 0)
         n_list = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the wave's DMA chunks have landed
     __syncthreads();
 
     // compass test over the 66x66 scored region (a 9-arc contains two adjacent compass points of one polarity), FOUR
@@ -173,7 +177,9 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         // tested tile columns [c_lo, c_hi) and scored rows [r_lo, r_hi): FAST's 3-pixel frame of the level
         const int c_lo = max(3, 7 - X0), c_hi = min(69, w - 3 - (X0 - 4));
         const int r_lo = max(0, 4 - Y0), r_hi = min(66, h - 3 - (Y0 - 1));
-        for(int i0 = 0; i0 < 66 * 18; i0 += 256)
+        // (only the items of rows below r_hi: the tiles of a level's last tile row are partly outside FAST's frame)
+        const int i_end = min(66, r_hi) * 18;
+        for(int i0 = (r_lo * 18) & ~255; i0 < i_end; i0 += 256)
         {
             const int i = i0 + tid;
             const int r = (i * 3641) >> 16, q = i - r * 18; // i / 18 for i < 16384
@@ -183,9 +189,9 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
                 const int lo4 = min(max(c_lo - 4 * q, 0), 4), hi4 = min(max(c_hi - 4 * q, 0), 4);
                 const uint32_t m4 = ((1u << hi4) - 1u) & ~((1u << lo4) - 1u);          // pixels j of the quad that are tested
                 const uint32_t colmask = ((m4 * 0x00204081u) & 0x01010101u) << 7;      // as the sign bits of the four bytes
-                const uint32_t* row = T + (r + 3) * 18 + q;
+                const uint32_t* row = T + (r + 3) * (kSP / 4) + (kSX / 4) + q;
                 const uint32_t L = row[-1], C = row[0], R = row[1];
-                const uint32_t U = row[-3 * 18], D = row[3 * 18];
+                const uint32_t U = row[-3 * (kSP / 4)], D = row[3 * (kSP / 4)];
                 const uint32_t Lf = __builtin_amdgcn_alignbyte(C, L, 1); // columns x-3 of the four pixels
                 const uint32_t Rt = __builtin_amdgcn_alignbyte(R, C, 3); // columns x+3
                 uint32_t k[2];
@@ -242,8 +248,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         const uint32_t two = *reinterpret_cast<const uint32_t*>(&list[2 * j]);
         const uint32_t ca = two & 0xFFFFu, cb = 2 * j + 1 < n ? two >> 16 : ca;
         const int ay = (int)(ca >> 8), ax = (int)(ca & 0xFF), by = (int)(cb >> 8), bx = (int)(cb & 0xFF);
-        const uint8_t* pa = &tile[ay * kSP + ax];
-        const uint8_t* pb = &tile[by * kSP + bx];
+        const uint8_t* pa = &tile[ay * kSP + kSX + ax];
+        const uint8_t* pb = &tile[by * kSP + kSX + bx];
         const uint32_t vv = ((uint32_t)pa[0] + kArcBias) | (((uint32_t)pb[0] + kArcBias) << 16);
         uint32_t e[16];
 #define MSLAM_E(k, off) e[k] = vv - ((uint32_t)pa[off] | ((uint32_t)pb[off] << 16))
