@@ -562,30 +562,40 @@ __device__ __forceinline__ void cv_select_run(uint32_t* keys, uint32_t* kept, fl
         *sel_cnt = (uint32_t)m2;
 }
 
-constexpr int kSelLds = 4096; // levels with at most this many FAST keypoints are selected entirely in LDS
+constexpr int kSelLds = 4096;      // levels with at most this many FAST keypoints are selected entirely in LDS
+constexpr int kSelLdsSmall = 1024; // ... and those with at most this many by the small instance (9 KB of LDS instead of 34)
 
-__global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ pyr, Geometry g, CvSelectArgs a)
+// Two instances on the same grid (as k_quadtree's classes): a (level, frame) pair is taken by the instance whose LDS
+// arrays its keypoints fit — the passes are barrier + LDS latency, so workgroups per CU set the rate — and the other
+// instance leaves at once (the count is one load).
+template <int KP, bool SMALL>
+__global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ pyr, Geometry g, CvSelectArgs a, int take_all)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
     __shared__ int s_thr;
-    __shared__ uint32_t l_keys[kSelLds];
-    __shared__ float l_resp[kSelLds];
-    const int level = blockIdx.x;
+    __shared__ uint32_t l_keys[KP];
+    __shared__ float l_resp[KP];
+    // Workgroups go to the 8 XCDs round-robin by linear id = frame * n_levels + blockIdx.x: with level = blockIdx.x and the
+    // usual 8 levels XCD 0 would get every level-0 pair (the heaviest: thousands of keys to sort) and XCD 7 every level-7
+    // one; rotating the level by the frame index gives every XCD the same mix.
+    const int level = (int)((blockIdx.x + blockIdx.y) % (unsigned)g.n_levels);
     const size_t frame = blockIdx.y + g.frame0;
     const LevelGeom& lv = g.lv[level];
     const size_t slot = frame * g.n_levels + level;
+    const int tid = threadIdx.x;
+    const int n_raw = (int)a.cand_cnt[slot];
+    if(!take_all && SMALL != (n_raw <= kSelLdsSmall))
+        return; // the other instance's pair
     uint32_t* cand = a.cand + slot * (size_t)a.cand_cap;
     uint32_t* sel = a.sel + slot * (size_t)a.cand_cap;
     float* sresp = a.sel_resp + slot * (size_t)a.cand_cap;
     const uint8_t* img = pyr + frame * g.slab + lv.offset;
-    const int tid = threadIdx.x;
-    const int n_raw = (int)a.cand_cnt[slot];
     if(n_raw > a.cand_cap && tid == 0)
         atomicOr(a.flags, kFlagCandOverflow);
     const int n = min(n_raw, a.cand_cap);
     const int quota = a.quota[level];
-    if(n <= kSelLds)
+    if(n <= KP)
     {
         for(int i = tid; i < n; i += 256)
             l_keys[i] = cand[i];
@@ -604,7 +614,11 @@ void launch_cv_select(const uint8_t* d_pyr, const Geometry& g, const CvSelectArg
 {
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_cv_select, dim3(g.n_levels, n_frames), dim3(256), 0, s, d_pyr, gg, a);
+    // a handful of frames (the synchronous single-frame call): one launch, the large instance takes every pair
+    const int take_all = n_frames < 8 ? 1 : 0;
+    hipLaunchKernelGGL((k_cv_select<kSelLds, false>), dim3(g.n_levels, n_frames), dim3(256), 0, s, d_pyr, gg, a, take_all);
+    if(!take_all)
+        hipLaunchKernelGGL((k_cv_select<kSelLdsSmall, true>), dim3(g.n_levels, n_frames), dim3(256), 0, s, d_pyr, gg, a, 0);
 }
 
 } // namespace mslam
