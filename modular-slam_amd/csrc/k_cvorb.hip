@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[72 * kSP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kSc];
-    __shared__ __attribute__((aligned(4))) uint16_t list[66 * 72 + 2];
-    constexpr uint32_t kDump = 66 * 72; // write-only slot for rejected pixels
+    __shared__ __attribute__((aligned(4))) uint16_t list[66 * 66 + 2]; // (at most every scored pixel survives: 20.1 KB in all, eight workgroups per CU)
+    constexpr uint32_t kDump = 66 * 66; // write-only slot for rejected pixels
     __shared__ uint32_t n_list;
 
     // XCD-aware mapping (as k_fast_cells): all tiles of a frame get ids with the same (id & 7) and meet in one L2

@@ -509,11 +509,13 @@ __global__ __launch_bounds__(QT) void k_quadtree_big(Geometry g, QuadArgs a, uns
     static_assert(kBigNodes * sizeof(uint2) >= (kMaxCellsPerLevel + 1) * sizeof(uint32_t), "cell offsets must fit");
     uint32_t* cell_off = reinterpret_cast<uint32_t*>(l_nodes_b);
 
-    // blockIdx.x counts the set bits of big_levels
+    // blockIdx.x counts the set bits of big_levels, rotated by the frame (as k_quadtree: with 2 or 4 big levels a plain
+    // count would tie each level to a fixed subset of the XCDs)
     int level = 0;
     {
         unsigned m = big_levels;
-        for(unsigned i = 0; i < blockIdx.x; ++i)
+        const unsigned which = (blockIdx.x + blockIdx.y) % gridDim.x;
+        for(unsigned i = 0; i < which; ++i)
             m &= m - 1;
         level = __ffs((int)m) - 1;
     }
