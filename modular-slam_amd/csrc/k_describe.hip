@@ -231,21 +231,25 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
         float my_scale = 1.f, my_resp = 0.f;
         {
             const int idx = base + lane * kStr; // position in the frame's concatenated keypoint list (:787-808)
-            int first = 0;               // list position of the level's first keypoint
+            // the level of list position idx = the number of levels whose cumulative count it has reached (one broadcast, one
+            // compare-and-add per level); the level's pitch / offset / scale and the list position of its first keypoint then
+            // come from the lanes that keep them (ds_bpermute: the LDS crossbar, not the vector ALU) — the select chain this
+            // replaces was ten vector instructions per level
             uint32_t lofs = 0;
-#pragma unroll 1
-            for(int l = 0; l < g.n_levels; ++l)
             {
-                // lane l holds level l's cumulative count and geometry (loaded once per wave, above): the level
-                // search is 4 broadcasts + selects per level, no memory access
-                const int cum = __builtin_amdgcn_readlane(lv_cum, l);
-                const bool here = idx >= first && idx < cum;
-                my_level = here ? l : my_level;
-                my_pitch = here ? bc(lv_pitch, l) : my_pitch;
-                lofs = here ? bc(lv_offset, l) : lofs;
-                my_scale = here ? __uint_as_float(bc(lv_scale, l)) : my_scale;
-                my_kp = here ? (uint32_t)(idx - first) : my_kp; // index inside the level, replaced by the word below
-                first = cum;
+                int lvl = 0;
+#pragma unroll 1
+                for(int l = 0; l + 1 < g.n_levels; ++l)
+                    lvl += idx >= __builtin_amdgcn_readlane(lv_cum, l) ? 1 : 0;
+                my_level = lvl;
+                // (every lane takes part in the exchange — a ds_bpermute returns 0 for a source lane that is switched off, so it
+                // must not sit in the arm of a per-lane condition)
+                const int prev_cum = __shfl(lv_cum, lvl > 0 ? lvl - 1 : 0);
+                const int first = lvl > 0 ? prev_cum : 0; // list position of the level's first keypoint
+                my_pitch = (uint32_t)__shfl((int)lv_pitch, lvl);
+                lofs = (uint32_t)__shfl((int)lv_offset, lvl);
+                my_scale = __uint_as_float((uint32_t)__shfl((int)lv_scale, lvl));
+                my_kp = (uint32_t)(idx - first); // index inside the level, replaced by the word below
             }
             if(lane < n_here)
             {

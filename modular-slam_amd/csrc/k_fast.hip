@@ -272,15 +272,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         {
             const unsigned long long m = bitmap[lane * 2] | ((unsigned long long)bitmap[lane * 2 + 1] << 32);
             const uint32_t cnt = (uint32_t)__popcll(m);
+            // inclusive scan of the row counts with DPP adds (VALU only: __shfl_up is a trip through the LDS crossbar per
+            // step, six of them in a row while the other three waves wait at the barrier)
             uint32_t inc = cnt;
-#pragma unroll
-            for(int o = 1; o < 64; o <<= 1)
-            {
-                const uint32_t t = __shfl_up(inc, o);
-                if(lane >= o)
-                    inc += t;
-            }
-            total = __shfl(inc, 63);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true); // row_shr:1
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true); // row_shr:2
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xE, true); // row_shr:4
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xC, true); // row_shr:8
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xA, 0xF, true); // row_bcast:15
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xC, 0xF, true); // row_bcast:31
+            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             if(total != 0)
             {
                 uint32_t* out = cell_kp + (frame * g.n_cells + cell_id) * (size_t)kCellCap;
