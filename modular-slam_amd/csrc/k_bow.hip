@@ -199,15 +199,30 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t* __restrict__
                     }
                 }
             }
+            // all-reduce over the group's 16 lanes = one DPP row: four rotate-and-min steps on the vector ALU (as __shfl_xor
+            // these were trips through the LDS crossbar, six per level with the two winner lookups, on a kernel that runs at
+            // the latency of its dependent chain).  Keys are unique (they carry the child index): exactly one lane holds the
+            // winner, and its (first child, child count) reach the others by the same rotations of a masked value.
+            static_assert(kBowGroup == 16, "the DPP row rotations below reduce over 16 lanes");
+            auto ror = [](uint32_t v, auto sh) {
+                constexpr int S = decltype(sh)::value;
+                return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + S, 0xF, 0xF, false); // row_ror:S
+            };
+            using std::integral_constant;
             uint32_t all = best[d];
-#pragma unroll
-            for(int o = kBowGroup / 2; o > 0; o >>= 1)
-                all = min(all, (uint32_t)__shfl_xor((int)all, o, kBowGroup));
-            // keys are unique (they carry the child index): exactly one lane of the group holds the winner
-            const int src = (int)((all & 0xFFFFu) % kBowGroup); // the lane that scored child (all & 0xFFFF)
+            all = min(all, ror(all, integral_constant<int, 1>{}));
+            all = min(all, ror(all, integral_constant<int, 2>{}));
+            all = min(all, ror(all, integral_constant<int, 4>{}));
+            all = min(all, ror(all, integral_constant<int, 8>{}));
+            const bool winner = best[d] == all;
+            uint32_t wf = winner ? best_fc[d] : 0u, wn = winner ? best_nc[d] : 0u;
+            wf |= ror(wf, integral_constant<int, 1>{}), wn |= ror(wn, integral_constant<int, 1>{});
+            wf |= ror(wf, integral_constant<int, 2>{}), wn |= ror(wn, integral_constant<int, 2>{});
+            wf |= ror(wf, integral_constant<int, 4>{}), wn |= ror(wn, integral_constant<int, 4>{});
+            wf |= ror(wf, integral_constant<int, 8>{}), wn |= ror(wn, integral_constant<int, 8>{});
             node[d] = fc[d] + (all & 0xFFFFu);
-            fc[d] = (uint32_t)__shfl((int)best_fc[d], src, kBowGroup);
-            nc[d] = (uint32_t)__shfl((int)best_nc[d], src, kBowGroup);
+            fc[d] = wf;
+            nc[d] = wn;
         }
     }
     if(sub < kBowDepth && i0 + sub < n)
