@@ -21,6 +21,29 @@ def test_kernel_names_map_to_stages():
     assert m("void mslam::k_describe<true>") == "describe" and m("void mslam::k_gray_blur<true>") == "gray"
     assert m("void mslam::k_resize_blur<false, 8, true>") == "resize" and m("void mslam::k_match_knn2_fp4<4, false>") == "match_knn2"
     assert m("__amd_rocclr_copyBuffer") is None
+    assert m("void mslam::k_quadtree<1024, 512, 1>") == "quadtree" and m("void mslam::k_cv_select<4096, false>") == "select"
+
+
+def test_every_kernel_of_the_committed_profile_has_a_stage():
+    """the kernel names of the newest committed rocprofv3 summary (profiles/r03_*_kernel_stats.csv) all map to a stage of the
+    step — a renamed or templated kernel must not silently drop out of the per-step counter summary — and the kernel the bench
+    line names for the dominant stage is one of them"""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_kernel_stats.csv")))
+    assert files, "no committed round-3 kernel stats"
+    names = [r["Name"].split("(")[0] for r in csv.DictReader(open(files[-1]))]
+    ours = [n for n in names if "mslam::" in n]
+    assert len(ours) >= 8
+    for n in ours:
+        assert bench.stage_of_kernel(n) is not None, n
+    # the dominant-stage label of the default line: "void mslam::k_resize_blur<false, N, true> (one launch per level)"
+    label = bench.STAGE_KERNEL["resize"].split(" (")[0]
+    pat = re.escape(label).replace("N", r"\d+")
+    assert any(re.fullmatch(pat, n) for n in ours), (label, ours)
+    for st in ("gray", "fast", "describe"):
+        assert bench.STAGE_KERNEL[st] in ours, (st, bench.STAGE_KERNEL[st])
 
 
 def test_summarize_counters_sums_launches_per_step(tmp_path):
