@@ -40,8 +40,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(66 * kScP + 15) / 16 * 16];
-    __shared__ __attribute__((aligned(4))) uint16_t cand[64 * 64 + 2];
-    constexpr uint32_t kDump = 64 * 64; // write-only slot for rejected pixels
+    __shared__ __attribute__((aligned(4))) uint16_t cand[64 * 64];
     __shared__ uint32_t bitmap[64 * 2];
     __shared__ uint32_t n_cand;
 
@@ -82,8 +81,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
     }
     // meanwhile: zero the score map (untested pixels must read 0, like FAST_t's zeroed row buffers) and the bitmap
-    for(int i = tid; i < (66 * kScP + 15) / 16; i += 256)
-        reinterpret_cast<uint4*>(sc)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // (its first 4 KB serve phase A as record segments and are cleared there)
+    if(tid < (66 * kScP + 15) / 16 - 256)
+        reinterpret_cast<uint4*>(sc)[256 + tid] = make_uint4(0u, 0u, 0u, 0u);
     if(tid < 128)
         bitmap[tid] = 0;
     if(tid == 0)
@@ -98,10 +98,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     {
         const int thr = pass == 0 ? ini_thr : min_thr;
 
-        // ---- A. compass test + compaction, four pixels per lane: a wave covers 4 rows x 64 columns per step.
-        //      Pixels are widened to u16 pairs and compared with packed 16-bit subtracts (sign bit = result).
+        // ---- A. compass test, four pixels per lane as ONE dword of bytes: a wave covers 4 rows x 64 columns per step.
+        //      v_lerp_u8 is a per-byte (a + b + r) >> 1 with no carries between the bytes; with b = ~centre it is the halved,
+        //      biased difference q = (p - c + 255) >> 1 of four pixels at once, and bit 7 of a second lerp against a
+        //      constant is a threshold test on q.  Halving costs one bit: q >= (t + 256) >> 1 is implied by p > c + t and
+        //      q <= (254 - t) >> 1 by p < c - t, so the test admits a few pixels the exact compass test would reject —
+        //      the list is a work queue for the exact arc score of phase B, any superset of the corners is correct.
+        //      Surviving GROUPS (dwords with a flag) are compacted by ballot into the wave's own segment of a record list
+        //      (flags in bits 7 / 15 / 23 / 31, (y << 8 | x) of the group's first pixel in the bits between); the sparse
+        //      records are then expanded to pixels by the same wave.  The segments live in the score map's storage (which
+        //      phase B wants zeroed anyway: every wave clears its own segment once it has expanded it).
         {
-            const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
+            typedef __attribute__((address_space(3))) uint32_t* lds32_t;
+            typedef __attribute__((address_space(3))) uint16_t* lds16_t;
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) u32x4_t* lds128_t;
+            // (everything lane-dependent of this phase is derived from an opaque copy of the thread id inside the pass loop:
+            // hoisted out of it, these values would hold registers through phases B and C, where the kernel sits at its 64)
+            uint32_t t_op = threadIdx.x;
+            asm volatile("" : "+v"(t_op));
+            const uint32_t ln = t_op & 63u;
+            const int wv = __builtin_amdgcn_readfirstlane((int)(t_op >> 6));
             // lane = (row sub, column group i4) of a step.  A full cell has 16 column groups (64 tested columns) and a wave
             // step covers 4 rows; the narrow cells that end a level's cell rows (and the short ones that end its cell columns)
             // use fewer groups per row and more rows per step — lg = log2(groups per row) — and only as many steps as they
@@ -109,104 +126,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             // work queue, the output order comes from the bitmap.)
             const int ngrp = (cw - 6 + 3) >> 2;                                             // column groups that hold a tested column
             const int lg = ngrp > 8 ? 4 : ngrp > 4 ? 3 : ngrp > 2 ? 2 : ngrp > 1 ? 1 : 0; // (wave-uniform)
-            const int i4 = lane & ((1 << lg) - 1), sub = lane >> lg;
+            const int i4 = (int)(ln & ((1u << lg) - 1u)), sub = (int)(ln >> lg);
             const int rps = 64 >> lg;                                                     // rows per wave step
-            const int n_steps = (ch - 6 + rps - 1) >> (6 - lg);                            // row steps of the cell, dealt to the waves round-robin
-            const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
-            // which of this lane's four columns 3+4i .. 6+4i are tested (x < cw - 3)
+            const int n_steps = (ch - 6 + rps - 1) >> (6 - lg);                            // row steps of the cell, dealt to the waves round-robin (<= 16)
+            const int tq = min(max(thr, 0), 254);
+            const uint32_t kb = (uint32_t)(256 - ((tq + 256) >> 1)) * 0x01010101u; // bit 7 of lerp(q, kb): q >= (t + 256) >> 1
+            const uint32_t kd = (uint32_t)(255 - ((254 - tq) >> 1)) * 0x01010101u; // bit 7 of lerp(q, kd): q >  (254 - t) >> 1
+            // which of this lane's four columns 3+4i .. 6+4i are tested (x < cw - 3), as bit 7 of the four bytes
             const int xl = 3 + 4 * i4;
-            // (as sign bits of the four bytes: the layout the packed compares deliver, see `keep` below)
             const uint32_t colmask = (xl < cw - 3 ? 0x80u : 0u) | (xl + 1 < cw - 3 ? 0x8000u : 0u) |
                                      (xl + 2 < cw - 3 ? 0x800000u : 0u) | (xl + 3 < cw - 3 ? 0x80000000u : 0u);
+            const uint32_t tile_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)tile;
+            const uint32_t cand_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)cand;
+            const uint32_t seg_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)sc + (uint32_t)wv * 1024u; // <= 4 steps x 64 groups per wave
+            int y = 3 + wv * rps + sub;
+            uint32_t row = tile_lds + (uint32_t)((y - 3) * kTileP + 4 * i4); // byte offset of dword i4 of tile row y - 3 (the topmost row a step reads)
+            uint32_t yx = (uint32_t)((y << 8) | xl);
+            uint32_t n_grp = 0; // (wave-uniform)
 #pragma unroll 1
-            for(int st = __builtin_amdgcn_readfirstlane(wave); st < n_steps; st += 4)
+            for(int st = wv; st < n_steps; st += 4, y += 4 * rps, row += (uint32_t)(4 * rps * kTileP), yx += (uint32_t)(4 * rps) << 8)
             {
-                const int y = 3 + st * rps + sub;
                 uint32_t keep = 0;
                 if(colmask != 0 && y < ch - 3)
                 {
                     // the four tested pixels are bytes 6+4i .. 9+4i of the row: dwords (i+1, i+2) shifted by two bytes
-                    const uint32_t* row = T + y * 20 + i4;
-                    const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];
-                    const uint32_t C = __builtin_amdgcn_alignbyte(d2, d1, 2);
-                    const uint32_t U = __builtin_amdgcn_alignbyte(row[2 - 3 * 20], row[1 - 3 * 20], 2);
-                    const uint32_t D = __builtin_amdgcn_alignbyte(row[2 + 3 * 20], row[1 + 3 * 20], 2);
+                    const lds32_t r = (lds32_t)row;
+                    const uint32_t d0 = r[60], d1 = r[61], d2 = r[62], d3 = r[63];
+                    const uint32_t nC = ~__builtin_amdgcn_alignbyte(d2, d1, 2);
+                    const uint32_t U = __builtin_amdgcn_alignbyte(r[2], r[1], 2);
+                    const uint32_t D = __builtin_amdgcn_alignbyte(r[122], r[121], 2);
                     const uint32_t Lf = __builtin_amdgcn_alignbyte(d1, d0, 3); // columns x-3 of the four pixels
                     const uint32_t Rt = __builtin_amdgcn_alignbyte(d3, d2, 1); // columns x+3
-                    uint32_t k[2];
-#pragma unroll
-                    for(int h = 0; h < 2; ++h)
-                    {
-                        const uint32_t sel = h == 0 ? 0x0c010c00u : 0x0c030c02u; // bytes (0,1) or (2,3) as u16 lanes
-                        typedef short s16x2 __attribute__((ext_vector_type(2)));
-                        // (the selector as a scalar operand: as a vector constant it holds a register the kernel, capped at 64, spills for)
-                        auto w = [&](uint32_t v) {
-                            uint32_t d;
-                            asm("v_perm_b32 %0, 0, %1, %2" : "=v"(d) : "v"(v), "s"(sel));
-                            return __builtin_bit_cast(s16x2, d);
-                        };
-                        const s16x2 t2 = __builtin_bit_cast(s16x2, thr2);
-                        const s16x2 cc = w(C), hi = cc + t2, lo = cc - t2;
-                        const s16x2 p0 = w(D), p4 = w(Rt), p8 = w(U), p12 = w(Lf);
-                        // brighter: (p0 or p8 > c + t) and (p4 or p12 > c + t)  <=>  min(max(p0, p8), max(p4, p12)) > c + t
-                        // darker : (p0 or p8 < c - t) and (p4 or p12 < c - t)  <=>  max(min(p0, p8), min(p4, p12)) < c - t
-                        // (packed 16-bit min / max; the comparisons are the sign bits of packed subtractions)
-                        const s16x2 mb = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12));
-                        const s16x2 md = __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
-                        k[h] = __builtin_bit_cast(uint32_t, (s16x2)(hi - mb)) | __builtin_bit_cast(uint32_t, (s16x2)(md - lo));
-                    }
-                    // the four results are the sign bits of the 16-bit lanes of k[0], k[1]: one v_perm puts their high bytes
-                    // side by side, pixel j's flag is then bit 8j + 7
-                    keep = __builtin_amdgcn_perm(k[1], k[0], 0x07050301u) & colmask;
+                    const uint32_t q0 = __builtin_amdgcn_lerp(D, nC, 0u), q8 = __builtin_amdgcn_lerp(U, nC, 0u);
+                    const uint32_t q4 = __builtin_amdgcn_lerp(Rt, nC, 0u), q12 = __builtin_amdgcn_lerp(Lf, nC, 0u);
+                    // brighter: (p0 or p8) and (p4 or p12);  not darker: (n0 and n8) or (n4 and n12) with n = "not darker"
+                    const uint32_t br = (__builtin_amdgcn_lerp(q0, kb, 0u) | __builtin_amdgcn_lerp(q8, kb, 0u)) &
+                                        (__builtin_amdgcn_lerp(q4, kb, 0u) | __builtin_amdgcn_lerp(q12, kb, 0u));
+                    const uint32_t nd = (__builtin_amdgcn_lerp(q0, kd, 0u) & __builtin_amdgcn_lerp(q8, kd, 0u)) |
+                                        (__builtin_amdgcn_lerp(q4, kd, 0u) & __builtin_amdgcn_lerp(q12, kd, 0u));
+                    keep = (br | ~nd) & colmask;
                 }
-                // compaction: wave-wide inclusive scan of the per-lane counts with DPP adds (no LDS, no ballots);
-                // every lane then issues its four stores unconditionally, rejected pixels into a dump slot
-                const uint32_t cnt = (uint32_t)__popc(keep);
-                uint32_t inc = cnt;
-                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true); // row_shr:1
-                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true); // row_shr:2
-                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xE, true); // row_shr:4
-                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xC, true); // row_shr:8
-                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xA, 0xF, true); // row_bcast:15
-                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xC, 0xF, true); // row_bcast:31
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                if(tot != 0)
+                const bool any = keep != 0;
+                const unsigned long long vote = __ballot(any);
+                if(any)
+                    ((lds32_t)seg_lds)[n_grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u))] =
+                        keep | yx;
+                n_grp += (uint32_t)__popcll(vote);
+            }
+            // expansion of the wave's records: pixel k of a record goes to the list slot given by the ballot of flag k
+            for(uint32_t i0 = 0; i0 < n_grp; i0 += 64)
+            {
+                const uint32_t rec = i0 + ln < n_grp ? ((lds32_t)seg_lds)[i0 + ln] : 0u;
+                const bool f0 = (rec & 0x80u) != 0, f1 = (rec & 0x8000u) != 0, f2 = (rec & 0x800000u) != 0, f3 = (int)rec < 0;
+                const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+                const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2),
+                               c3 = (uint32_t)__popcll(m3);
+                // one lane reserves the wave's range of the list.  Written out by hand: around `if(lane == 0) atomicAdd(..)`
+                // the compiler's atomic optimiser builds a wave reduction for a value that is wave-uniform already.
+                uint32_t base;
                 {
-                    // one lane reserves the wave's range of the list.  Written out by hand: around `if(lane == 0) atomicAdd(..)`
-                    // the compiler's atomic optimiser builds a wave reduction (mbcnt, bcnt, a multiply, two exec-mask
-                    // regions: ~8 vector instructions per step) for a value that is wave-uniform already.
-                    uint32_t base;
-                    {
-                        uint32_t got;
-                        unsigned long long save;
-                        const uint32_t add = tot; // (a vector register copy of the wave-uniform count)
-                        asm volatile("s_mov_b64 %1, exec\n\t"
-                                     "s_mov_b64 exec, 1\n\t"
-                                     "ds_add_rtn_u32 %0, %2, %3\n\t"
-                                     "s_waitcnt lgkmcnt(0)\n\t"
-                                     "s_mov_b64 exec, %1"
-                                     : "=&v"(got), "=&s"(save)
-                                     : "v"(n_cand_lds), "v"(add)
-                                     : "memory");
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                    }
-                    uint32_t pos = base + inc - cnt;
-                    const uint32_t yx = (uint32_t)((y << 8) | xl);
-                    // slot = kept ? pos : dump as ONE v_bfi_b32 on an all-ones / all-zeros mask (v_bfe_i32), and the
-                    // running slot advanced with a 24-bit multiply-add on the same mask: 3 VALU ops per store instead of
-                    // the compare + select + shift chains the compiler builds (which also cost wait states here)
-                    uint32_t pos2 = 2u * pos; // byte offset into cand[]
-                    const uint32_t dump2 = 2u * kDump;
-#pragma unroll
-                    for(int k = 0; k < 4; ++k)
-                    {
-                        const int m = __builtin_amdgcn_sbfe((int)keep, 8 * k + 7, 1); // -1 when kept
-                        uint32_t slot2;
-                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(slot2) : "v"(m), "v"(pos2), "s"(dump2));
-                        *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(cand) + slot2) = (uint16_t)(yx + k);
-                        pos2 = (uint32_t)__mul24(m, -2) + pos2;
-                    }
+                    uint32_t got;
+                    unsigned long long save;
+                    const uint32_t add = c0 + c1 + c2 + c3; // (a vector register copy of the wave-uniform count)
+                    asm volatile("s_mov_b64 %1, exec\n\t"
+                                 "s_mov_b64 exec, 1\n\t"
+                                 "ds_add_rtn_u32 %0, %2, %3\n\t"
+                                 "s_waitcnt lgkmcnt(0)\n\t"
+                                 "s_mov_b64 exec, %1"
+                                 : "=&v"(got), "=&s"(save)
+                                 : "v"(n_cand_lds), "v"(add)
+                                 : "memory");
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
                 }
+                const uint32_t v = rec & 0x7F7Fu;
+                const lds16_t L = (lds16_t)cand_lds;
+                if(f0)
+                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint16_t)v;
+                base += c0;
+                if(f1)
+                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint16_t)(v + 1);
+                base += c1;
+                if(f2)
+                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u))] = (uint16_t)(v + 2);
+                base += c2;
+                if(f3)
+                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, 0u))] = (uint16_t)(v + 3);
+            }
+            // the segment's storage becomes score map again (bytes beyond the four segments were cleared at the start)
+            {
+                uint32_t z = 0;
+                asm volatile("" : "+v"(z)); // (a zero made here: hoisted, a uint4 of zeros holds four registers through the kernel)
+                ((lds128_t)seg_lds)[ln] = u32x4_t{z, z, z, z};
             }
         }
         __syncthreads();

@@ -1149,7 +1149,6 @@ double mso_bow_score_l1(const uint32_t* w1, const double* v1, int n1, const uint
 }
 
 /* ==== cv::ORB detector mode (orb_feature.cpp:25,33-65 -> OpenCV 4.8.1 features2d/src/orb.cpp) ================ */
-#include "../include/mslam_sincos.h"
 
 void mso_cvorb_default_params(mso_cvorb_params* p)
 {
@@ -1287,8 +1286,11 @@ void mso_cvorb_descriptor(const uint8_t* blurred, int step, int x, int y, float 
 {
     float angle = angle_deg;
     angle *= (float)(3.1415926535897932384626433832795 / 180.f);
-    float a, b;
-    mslam_sincos_f32(angle, &b, &a); /* a = cos, b = sin (the reference: host cosf / sinf) */
+    /* a = cos, b = sin.  The reference calls the host libm's cosf / sinf (implementation-defined in the last bit); the
+     * oracle takes the double-precision libm routines rounded to float, i.e. the correctly rounded float values — an
+     * implementation INDEPENDENT of include/mslam_sincos.h, which only the product (k_describe.hip) evaluates, so the
+     * GPU-vs-oracle comparison of the cv::ORB mode's descriptors is not a self-comparison. */
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
     const uint8_t* center = blurred + (size_t)y * step + x;
 #define CV_VALUE(s)                                                                                                    \
     (center[cv_round_f((float)k_pattern[(s)] * b + (float)k_pattern[(s) + 1] * a) * step +                            \
@@ -1410,7 +1412,9 @@ int mso_cvorb_detect(const uint8_t* bgr, int W, int H, const mso_cvorb_params* p
     return rc;
 }
 
-/* test hooks: the shared routine and the host libm's float cos/sin (what the reference calls) */
+/* test hooks: the PRODUCT's routine compiled for the host (so that a CPU test can examine it against libm; no algorithm of
+ * the oracle calls it) and the host libm's float cos/sin (what the reference calls) */
+#include "../include/mslam_sincos.h"
 void mso_sincos_f32(float x, float* s, float* c) { mslam_sincos_f32(x, s, c); }
 void mso_libm_sincosf(float x, float* s, float* c)
 {

@@ -115,7 +115,9 @@ void mso_backproject(const uint16_t* depth, int width, int height, float factor,
  *  - output ORDER: retainBest() uses std::nth_element + std::partition, so the reference's order inside a level
  *    is implementation-defined; the kept SET is well defined (response >= the n-th largest, ties kept).  The oracle
  *    emits each level in FAST's raster order (y, then x);
- *  - cos/sin of the keypoint angle come from include/mslam_sincos.h instead of the host libm's cosf/sinf. */
+ *  - cos/sin of the keypoint angle are the correctly rounded float values ((float)cos((double)a) from the host libm's
+ *    double routines) instead of the host libm's cosf/sinf, whose last bit is implementation-defined; the product
+ *    evaluates include/mslam_sincos.h, an independent implementation of the same correctly rounded values. */
 typedef struct
 {
     int n_features;     /* 1000  orb_feature.cpp:25            */
@@ -141,7 +143,7 @@ int mso_cvorb_level_keypoints(const uint8_t* img, int w, int h, const mso_cvorb_
 int mso_cvorb_detect(const uint8_t* bgr, int W, int H, const mso_cvorb_params* p, int max_out, float* xy, uint8_t* desc,
                      int32_t* octave, float* angle, float* response, int* n_out);
 
-void mso_sincos_f32(float x, float* s, float* c);   /* include/mslam_sincos.h */
+void mso_sincos_f32(float x, float* s, float* c);   /* include/mslam_sincos.h (the product's routine, host build: test hook only) */
 void mso_libm_sincosf(float x, float* s, float* c); /* host libm sinf / cosf */
 
 /* ---- DBoW3 (rmsalinas/DBow3 master, conan_recipes/dbow3/conanfile.py:9,18) ---------------- */
