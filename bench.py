@@ -69,6 +69,8 @@ def stage_of_kernel(name):
             return st
     return None
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_per_step.json")  # tools/summarize_counters.py
+K2000_MIN_AREA = 984   # 640x480: 1986 keypoints per frame on the synthetic stream (1000, the reference default: ~1890)
+CFG4_MIN_AREA = 6340   # 1280x720, 8 levels: ~2015 keypoints per frame
 CLOCK_HZ = 2.4e9  # MI355X max shader clock (MI355X_MICROARCH.md); the vector-ALU issue figures are quoted at this clock
 
 
@@ -430,7 +432,12 @@ def main():
         sb = stage_bytes(ctx, B, kp_b, cand_b, 10, a.voc_levels)   # per step (B frames)
         if cv:  # the selection stage of the cv::ORB mode stands where the quadtree is (same order of bytes)
             sb["select"] = sb["quadtree"]
-        dom = max((k for k in acc if k in sb), key=acc.get)
+        # the kernel that binds: the stage with the largest duration ALONE on the GPU (the serialized pass; an in-place
+        # interval on one of the two chunk streams is inflated unevenly by the sibling chunk's kernels), falling back to
+        # the in-place sums when the serialized pass did not run (--no-extras)
+        ser = extras.get("stages_ms_serialized", {})
+        ser_ok = {k: v for k, v in ser.items() if k in sb and k in acc}
+        dom = max(ser_ok, key=ser_ok.get) if ser_ok else max((k for k in acc if k in sb), key=acc.get)
         fpl = B / per_step[dom]                                    # frames per launch of the dominant stage
         bytes_per_launch = sb[dom] / per_step[dom]
         achieved = bytes_per_launch / (avg[dom] * 1e-3) / 1e9
@@ -439,17 +446,19 @@ def main():
         traffic = int(traffic_step / per_step[dom]) if traffic_step is not None else None
         # the kernel's own duration: alone on the GPU when the serialized pass ran (in place it shares the GPU with
         # the sibling chunk's kernels, which would halve the fraction)
-        ser = extras.get("stages_ms_serialized", {})
         alone_step_ms = ser.get(dom)                                # ms per step with every launch of the stage alone
         frac_alone = (sb[dom] / (alone_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if alone_step_ms else None
         v_ms = valu_issue_ms(dom, B)
         valu_frac_alone = (v_ms / alone_step_ms) if (v_ms is not None and alone_step_ms) else None
         step_valu = valu_issue_ms(None, B)
         step_ms = dt_max / a.steps * 1e3
-        # what binds the dominant kernel: the larger of its HBM fraction and its vector-ALU issue fraction (both alone)
+        # `bound` names the roofline that achieved / peak / unit / frac are quoted against (HBM: BASELINE.json's metric);
+        # `binding_limit` says what actually binds the dominant kernel: the larger of its HBM fraction and its vector-ALU
+        # issue fraction (both alone)
         bound = "hbm"
+        binding = "hbm"
         if valu_frac_alone is not None and frac_alone is not None and valu_frac_alone > frac_alone:
-            bound = "valu"
+            binding = "valu-issue"
         limiter = "not HBM (see DESIGN.md §4: every stage but gray is issue- or latency-bound)"
         if valu_frac_alone is not None:
             limiter = ("vector-ALU issue %.0f %% of the kernel's duration alone on the GPU (SQ_INSTS_VALU x 4 cycles at 2.4 GHz, "
@@ -457,7 +466,18 @@ def main():
                            100 * valu_frac_alone, os.path.basename(PMC_PROFILE), 100 * frac_alone))
             if dom == "describe":
                 limiter += "; the rest of its time is the L2 -> LDS window gathers (DESIGN.md §4.6)"
-        roofline = {"kernel": kern, "stage": dom, "bound": bound, "achieved": round(achieved, 1),
+        # per-stage table: every stage alone on the GPU against both roofs, and its counter traffic over its algorithmic bytes
+        stage_table = {}
+        for k, ms_alone in ser.items():
+            if k not in sb or not ms_alone:
+                continue
+            row = {"ms_alone": round(ms_alone, 4), "hbm_frac_alone": round(sb[k] / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            vk = valu_issue_ms(k, B)
+            row["valu_issue_frac_alone"] = round(vk / ms_alone, 3) if vk is not None else None
+            tk, _ = pmc_traffic(k, B)
+            row["traffic_over_algorithmic"] = round(tk / sb[k], 2) if tk is not None and sb[k] else None
+            stage_table[k] = row
+        roofline = {"kernel": kern, "stage": dom, "bound": bound, "binding_limit": binding, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "frac_alone": round(frac_alone, 4) if frac_alone is not None else None,
                     "valu_issue_frac_alone": round(valu_frac_alone, 3) if valu_frac_alone is not None else None,
@@ -466,6 +486,9 @@ def main():
                     "step_valu_issue_ms": round(step_valu, 3) if step_valu is not None else None,
                     "traffic": traffic, "traffic_source": traffic_note,
                     "limiter": limiter,
+                    "stage_chosen_by": "largest duration alone on the GPU (stages_ms_serialized)" if ser_ok else
+                                       "largest in-place time per step (no serialized pass in this run)",
+                    "stages": stage_table,
                     "launches_per_step": per_step[dom], "frames_per_launch": fpl, "avg_ms": round(avg[dom], 4),
                     # a "launch" of the resize stage is one kernel per level > 0: rocprofv3's per-kernel average is avg_ms / this
                     "kernels_per_launch": (a.levels - 1) if dom == "resize" else 1,
@@ -561,14 +584,18 @@ def main():
             print(json.dumps(line), flush=True)
             return True
 
+    # the fallback line is a snapshot of the headline taken NOW, on the main thread, before any extra leg runs: the
+    # watchdog thread only copies it, it never calls into the context or reads `extras` while the main thread works on them
+    headline = make_line({}, with_cpu=False) if (world > 1 and rank == 0) else None
     if world > 1:
         def give_up():
-            # a collective / GPU step of the extras never completed: that is a hang, not a pass.  Rank 0 still prints
-            # the headline (the timed region was complete) with the reason, and EVERY rank exits non-zero.
+            # a collective / GPU step after the timed region never completed: that is a hang, not a pass.  Rank 0 still
+            # prints the headline (the timed region was complete) with the reason, and EVERY rank exits non-zero.
             if rank == 0 and not printed[0]:
-                emit(make_line({"extras_error": "the legs after the timed region did not finish within %d s "
-                                                "(hung collective or GPU step): exit code 3" % a.extras_timeout},
-                               with_cpu=False))
+                line = dict(headline)
+                line["extras_error"] = ("the legs after the timed region did not finish within %d s (hung collective or GPU "
+                                        "step): exit code 3" % a.extras_timeout)
+                emit(line)
             os._exit(3)
         watchdog = threading.Timer(a.extras_timeout, give_up)
         watchdog.daemon = True
@@ -753,12 +780,79 @@ def main():
                 # cfg3: the same stream + DBoW3 loop scoring against a 1e6-word vocabulary every frame (k = 10, L = voc_levels)
                 voc = synth.make_vocabulary(10, a.voc_levels, seed=77)
                 ctx.bow_load(voc)
-                ctx.bow_db_reserve(16 * B)  # the leg adds 15 batches of entries: no storage doubling inside the timed steps
+                ctx.bow_db_reserve(32 * B)  # the leg adds 2 + 10 + 1 + 10 + 3 = 26 batches of entries: no storage doubling inside its timed steps
                 extras["cfg3"] = leg("cfg3", ctx, lambda i: step(i, bow=True), B, 10, counts_per_batch[0], cand_per_batch[0],
                                      a.voc_levels,
                                      "cfg3: the cfg2 step + DBoW3 transform (k=10, L=%d: %d words), tf-idf + L1 vectors, scores vs the "
                                      "last 64 frames, inverted-file adds" % (a.voc_levels, 10 ** a.voc_levels))
-                del voc
+                # cfg2 at BASELINE.json's nominal K: the quadtree's stop area tuned so that a frame keeps 2000 +- 2 % keypoints
+                # (SURVEY.md §8d "min-area tuned so K ~ 2000"; the headline keeps the reference's default 1000 -> ~1880)
+                ts2 = torch.cuda.Stream()
+                ctx2 = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=K2000_MIN_AREA,
+                                   max_keypoints=4096 * k_scale, max_candidates=16384 * area, device=dev, stream=ts2.cuda_stream)
+
+                def step2(i):
+                    off2 = (i % n_batches) * B
+                    ctx2.detect_batch_dev(d_frames.data_ptr() + off2 * frame_bytes, B)
+                    ctx2.match_batch_dev(0.7, True)
+                    ctx2.backproject_batch_dev(d_depth.data_ptr() + off2 * depth_bytes)
+                step2(0)
+                ctx2.sync()
+                kp2 = int(pkg.read_device(ctx2, ctx2.batch_view().count, (B,), np.int32).sum())
+                cand2 = int(ctx2.debug_counts(pkg.DBG_CANDIDATES, B).sum())
+                extras["cfg2_k2000"] = leg("cfg2_k2000", ctx2, step2, B, 10, kp2, cand2, a.voc_levels,
+                                           "cfg2 with the quadtree stop area tuned to BASELINE.json's nominal 2000 keypoints per "
+                                           "frame (min-area %d instead of the reference default 1000), otherwise the headline step" %
+                                           K2000_MIN_AREA)
+                ctx2.close()
+
+                # cfg4, ONE rank of it: a 1280x720 stream, 8 levels, ~2000 keypoints per frame, the cfg3 BoW step and the device
+                # side of the cross-stream exchange (pack -> the world-1 "all-gather" = a device copy -> cross scores)
+                W4, H4, B4 = 1280, 720, 250
+                f4 = synth.make_stream(B4, W4, H4, seed=1234)
+                d4 = torch.from_numpy(f4).cuda()
+                dd4 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W4, H4, seed=1234)[0]] * B4)).view(np.int16)).cuda()
+                area4 = -(-W4 * H4 // (640 * 480))
+                ts4 = torch.cuda.Stream()
+                ctx4 = pkg.Context(width=W4, height=H4, max_batch=B4, n_levels=8, min_node_area=CFG4_MIN_AREA,
+                                   max_keypoints=4096 * area4, max_candidates=16384 * area4, device=dev, stream=ts4.cuda_stream)
+                ctx4.bow_load(voc)
+                ctx4.bow_db_reserve(32 * B4)
+                cross4 = CrossStreamLoopCandidates(k_max=2048)
+
+                def step4(i):
+                    ctx4.detect_batch_dev(d4.data_ptr(), B4)
+                    ctx4.match_batch_dev(0.7, True)
+                    ctx4.backproject_batch_dev(dd4.data_ptr())
+                    ctx4.bow_batch_dev(True)
+                    cross4.step_gpu(ctx4, ts4, B4)
+                step4(0)
+                cross4.finish(ts4)
+                ctx4.sync()
+                kp4 = int(pkg.read_device(ctx4, ctx4.batch_view().count, (B4,), np.int32).sum())
+                cand4 = int(ctx4.debug_counts(pkg.DBG_CANDIDATES, B4).sum())
+                c4 = cross4.collectives
+                l4 = leg("cfg4_one_rank", ctx4, step4, B4, 10, kp4, cand4, a.voc_levels,
+                         "cfg4, one rank: synthetic 1280x720 RGB-D stream (%d distinct frames), 8 levels, min-area %d, extract + match + "
+                         "back-projection + DBoW3 (k=10, L=%d) vectors / scores / inverted-file adds + exchange (pack, world-1 gather, "
+                         "cross-stream scores)" % (B4, CFG4_MIN_AREA, a.voc_levels))
+                cross4.finish(ts4)
+                n_coll = cross4.collectives - c4
+                # the exchange alone: pack + gather + cross score of one batch, on the streams the step uses
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(10):
+                    cross4.step_gpu(ctx4, ts4, B4)
+                cross4.finish(ts4)
+                torch.cuda.synchronize()
+                l4["exchange"] = {"bytes_per_collective": 4 * set_dwords(B4, cross4.k_max), "k_max": cross4.k_max,
+                                  "collectives_per_step": 1.0 if n_coll else 0.0,
+                                  "ms_per_batch_alone": (time.perf_counter() - t0) / 10 * 1e3,
+                                  "what": "mslam_hip_bow_pack_dev -> all_gather_into_tensor (world 1: a device copy of the set) -> "
+                                          "mslam_hip_bow_cross_score_packed_dev on the communication stream"}
+                extras["cfg4_one_rank"] = l4
+                ctx4.close()
+                del d4, dd4, f4, voc
                 # cfg5: 1920x1080, 3 levels, ~10 k keypoints per frame, k = 2 matcher with ratio test (64 M+ distances per frame)
                 W5, H5, B5 = 1920, 1080, 64
                 f5 = synth.make_stream(B5, W5, H5, seed=4321)
@@ -828,15 +922,16 @@ def main():
     except Exception as e:  # noqa: BLE001 - any failure of an extra leg must not cost the headline
         extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
 
-    if watchdog is not None:
-        watchdog.cancel()  # the extras are over: from here on only the main thread builds a line
-    out = make_line(extras) if rank == 0 else None
+    # the line leaves the process BEFORE the context is closed and before the closing barrier: a peer that hung or died in
+    # its extras can no longer cost it.  The watchdog stays armed over close / barrier / destroy (a rank stuck there exits 3).
+    if rank == 0:
+        emit(make_line(extras))
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        emit(out)
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

@@ -58,5 +58,39 @@ __device__ __forceinline__ void arc_score2(const uint32_t (&e)[16], int& sa, int
     sb = max((int)(q0 >> 16) - kArcBias, kArcBias - (int)(q1 >> 16)) - 1;
 }
 
+// The same score from the RAW circle pixels p[k] (two candidates per register, 16-bit halves holding 0..255):
+//   S = max(c - min over arcs of max(p), max over arcs of min(p) - c) - 1
+// — min / max commute with the subtraction from the centre, so the sixteen differences are never formed.  The halves are
+// f16 DENORMALS here (patterns 0x0000..0x00FF): they order like their integers as long as the f16 denormal mode keeps
+// them (the AMDGPU default for f16 / f64; the kernels that use this are compiled without -fgpu-flush-denormals-to-zero,
+// and tests/test_gpu_parity.py would see a flush at once: every score would collapse to the centre).
+__device__ __forceinline__ void arc_score2_raw(const uint32_t (&p)[16], int ca, int cb, int& sa, int& sb)
+{
+    uint32_t mn3[16], mx3[16];
+#pragma unroll
+    for(int i = 0; i < 16; ++i)
+    {
+        mn3[i] = pk_min3(p[i], p[(i + 1) & 15], p[(i + 2) & 15]);
+        mx3[i] = pk_max3(p[i], p[(i + 1) & 15], p[(i + 2) & 15]);
+    }
+    uint32_t mn9[16], mx9[16];
+#pragma unroll
+    for(int i = 0; i < 16; ++i)
+    {
+        mn9[i] = pk_min3(mn3[i], mn3[(i + 3) & 15], mn3[(i + 6) & 15]);
+        mx9[i] = pk_max3(mx3[i], mx3[(i + 3) & 15], mx3[(i + 6) & 15]);
+    }
+    uint32_t q0 = pk_max3(mn9[0], mn9[1], mn9[2]), q1 = pk_min3(mx9[0], mx9[1], mx9[2]);
+#pragma unroll
+    for(int i = 3; i < 15; i += 2)
+    {
+        q0 = pk_max3(q0, mn9[i], mn9[i + 1]);
+        q1 = pk_min3(q1, mx9[i], mx9[i + 1]);
+    }
+    q0 = pk_max3(q0, mn9[15], mn9[15]); // max over the arcs of the arc's darkest pixel
+    q1 = pk_min3(q1, mx9[15], mx9[15]); // min over the arcs of the arc's brightest pixel
+    sa = max(ca - (int)(q1 & 0xFFFFu), (int)(q0 & 0xFFFFu) - ca) - 1;
+    sb = max(cb - (int)(q1 >> 16), (int)(q0 >> 16) - cb) - 1;
+}
 
 } // namespace mslam

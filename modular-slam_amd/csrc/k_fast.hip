@@ -24,8 +24,8 @@
 namespace mslam
 {
 
-constexpr int kTileP = 80; // tile row pitch in bytes: five 16-byte LDS-DMA chunks from column x0 - 3 on (a 16-byte boundary),
-constexpr int kTileX = 3;  // i.e. tile byte = column + 3: the tested columns 3+4i .. 6+4i are bytes 6+4i .. 9+4i
+constexpr int kTileP = 80; // tile row pitch in bytes: five 16-byte LDS-DMA chunks from column x0 - 1 on,
+constexpr int kTileX = 1;  // i.e. tile byte = column + 1: the tested columns 3+4i .. 6+4i are bytes 4+4i .. 7+4i, dword i + 1
 constexpr int kScP = 68;   // score-map row pitch
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ __attribute__((aligned(16))) uint8_t sc[(66 * kScP + 15) / 16 * 16];
     __shared__ __attribute__((aligned(4))) uint16_t cand[64 * 64];
     __shared__ uint32_t bitmap[64 * 2];
-    __shared__ uint32_t n_cand;
+    constexpr uint32_t kPassCap = 512;
+    __shared__ uint16_t plist[kPassCap]; // candidates whose score reaches the threshold (what phase C looks at)
+    __shared__ uint32_t n_cand, n_pass;
 
     // XCD-aware mapping: workgroups are handed to the 8 XCDs round-robin by linear id, and neighbouring cells share
     // 128-byte lines (a 70-byte cell row straddles two of them, its neighbours use the rest).  With cells of one
@@ -59,13 +61,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int cw = c.cw, ch = c.ch;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // stage the sub-image by LDS-DMA: the cell's rows start at column x0 - 3 = 16 + 64 j, a 16-byte boundary of the level
-    // plane (pitch and level offset are multiples of 16), so a row is five 16-byte chunks that go from global memory
-    // straight into the tile — no registers, no vector instructions for the copy (round 2 staged through registers
-    // with a 2-byte shift to make the tested columns dword-aligned: ~45 instructions per wave; the unshifted image
-    // costs phase A three more v_alignbyte per step).  Chunk t = (row t / 5, chunk t % 5) lands at tile + 16 t.
+    // stage the sub-image by LDS-DMA: a row is five 16-byte chunks that go from global memory straight into the tile — no
+    // registers, no vector instructions for the copy.  The chunks start at column x0 - 1 = 18 + 64 j, which puts the
+    // tested columns on dword boundaries of the tile (phase A reads centre / upper / lower pixels without a byte shift) and
+    // is NOT an aligned address: LDS-DMA takes any byte address (tools/experiments/dma_align_probe.hip: every shift 0..19
+    // exact, dwordx4 and dword).  (Round 3 started at x0 - 3, a 16-byte boundary, and paid three v_alignbyte per step.)
+    // Chunk t = (row t / 5, chunk t % 5) lands at tile + 16 t; the last chunk of a row ends 9 bytes beyond the cell (the
+    // next cell's pixels, or the slab's pad behind the last row).
     {
-        const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - 3);
+        const uint8_t* src = pyr + frame * g.slab + lv.offset + (size_t)c.y0 * lv.pitch + (c.x0 - kTileX);
         const int n_chunks = ch * 5;
 #pragma unroll
         for(int p = 0; p < 2; ++p)
@@ -87,12 +91,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if(tid < 128)
         bitmap[tid] = 0;
     if(tid == 0)
-        n_cand = 0;
+        n_cand = 0, n_pass = 0;
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the wave's DMA chunks have landed
     __syncthreads();
 
     // LDS byte offset of the list's fill counter (for the hand-written reservation in phase A)
     const uint32_t n_cand_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(&n_cand);
+    const uint32_t n_pass_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(&n_pass);
     uint32_t total = 0;
     for(int pass = 0; pass < 2; ++pass)
     {
@@ -134,8 +139,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const uint32_t kd = (uint32_t)(255 - ((254 - tq) >> 1)) * 0x01010101u; // bit 7 of lerp(q, kd): q >  (254 - t) >> 1
             // which of this lane's four columns 3+4i .. 6+4i are tested (x < cw - 3), as bit 7 of the four bytes
             const int xl = 3 + 4 * i4;
-            const uint32_t colmask = (xl < cw - 3 ? 0x80u : 0u) | (xl + 1 < cw - 3 ? 0x8000u : 0u) |
-                                     (xl + 2 < cw - 3 ? 0x800000u : 0u) | (xl + 3 < cw - 3 ? 0x80000000u : 0u);
+            const int n_col = min(max(cw - 3 - xl, 0), 4);
+            const uint32_t colmask = (uint32_t)(0x80808080ull >> (8 * (4 - n_col)));
             const uint32_t tile_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)tile;
             const uint32_t cand_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)cand;
             const uint32_t seg_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)sc + (uint32_t)wv * 1024u; // <= 4 steps x 64 groups per wave
@@ -149,14 +154,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 uint32_t keep = 0;
                 if(colmask != 0 && y < ch - 3)
                 {
-                    // the four tested pixels are bytes 6+4i .. 9+4i of the row: dwords (i+1, i+2) shifted by two bytes
+                    // the four tested pixels are dword i + 1 of the row
                     const lds32_t r = (lds32_t)row;
-                    const uint32_t d0 = r[60], d1 = r[61], d2 = r[62], d3 = r[63];
-                    const uint32_t nC = ~__builtin_amdgcn_alignbyte(d2, d1, 2);
-                    const uint32_t U = __builtin_amdgcn_alignbyte(r[2], r[1], 2);
-                    const uint32_t D = __builtin_amdgcn_alignbyte(r[122], r[121], 2);
-                    const uint32_t Lf = __builtin_amdgcn_alignbyte(d1, d0, 3); // columns x-3 of the four pixels
-                    const uint32_t Rt = __builtin_amdgcn_alignbyte(d3, d2, 1); // columns x+3
+                    const uint32_t d0 = r[60], d1 = r[61], d2 = r[62];
+                    const uint32_t nC = ~d1, U = r[1], D = r[121];
+                    const uint32_t Lf = __builtin_amdgcn_alignbyte(d1, d0, 1); // columns x-3 of the four pixels
+                    const uint32_t Rt = __builtin_amdgcn_alignbyte(d2, d1, 3); // columns x+3
                     const uint32_t q0 = __builtin_amdgcn_lerp(D, nC, 0u), q8 = __builtin_amdgcn_lerp(U, nC, 0u);
                     const uint32_t q4 = __builtin_amdgcn_lerp(Rt, nC, 0u), q12 = __builtin_amdgcn_lerp(Lf, nC, 0u);
                     // brighter: (p0 or p8) and (p4 or p12);  not darker: (n0 and n8) or (n4 and n12) with n = "not darker"
@@ -230,10 +233,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const int ay = (int)(ca >> 8), ax = (int)(ca & 0xFF), by = (int)(cb >> 8), bx = (int)(cb & 0xFF);
             const uint8_t* pa = &tile[ay * kTileP + ax + kTileX];
             const uint8_t* pb = &tile[by * kTileP + bx + kTileX];
-            // (centre + bias) of both pixels; the subtraction below never borrows from the upper half
-            const uint32_t vv = ((uint32_t)pa[0] + kArcBias) | (((uint32_t)pb[0] + kArcBias) << 16);
+            // circle pixel k of both candidates side by side in one register (16-bit halves): the byte loads write the halves
+            // directly (ds_read_u8_d16 / _d16_hi), no vector instruction packs them
+            typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
             uint32_t e[16];
-#define MSLAM_E(k, off) e[k] = vv - ((uint32_t)pa[off] | ((uint32_t)pb[off] << 16))
+#define MSLAM_E(k, off)                                                                    \
+    {                                                                                      \
+        u16x2_t v2;                                                                        \
+        v2.x = (unsigned short)pa[off];                                                    \
+        v2.y = (unsigned short)pb[off];                                                    \
+        e[k] = __builtin_bit_cast(uint32_t, v2);                                           \
+    }
             MSLAM_E(0, 3 * kTileP);
             MSLAM_E(1, 3 * kTileP + 1);
             MSLAM_E(2, 2 * kTileP + 2);
@@ -252,18 +262,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             MSLAM_E(15, 3 * kTileP - 1);
 #undef MSLAM_E
             int sa, sb;
-            arc_score2(e, sa, sb);
-            if(sa >= thr && sa > 0)
+            arc_score2_raw(e, (int)pa[0], (int)pb[0], sa, sb);
+            const bool pass_a = sa >= thr && sa > 0, pass_b = sb >= thr && sb > 0 && 2 * j + 1 < n;
+            if(pass_a)
                 sc[(ay - 2) * kScP + (ax - 2)] = (uint8_t)sa;
-            if(sb >= thr && sb > 0)
+            if(pass_b)
                 sc[(by - 2) * kScP + (bx - 2)] = (uint8_t)sb;
+            // the passing pixels (about a third of the list) go to a second, short list: phase C then runs one or two dense
+            // wave-iterations instead of one per 64 candidates
+            const unsigned long long ma = __ballot(pass_a), mb = __ballot(pass_b);
+            const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
+            if(na + nb != 0)
+            {
+                uint32_t got;
+                unsigned long long save;
+                const uint32_t add = na + nb;
+                asm volatile("s_mov_b64 %1, exec\n\t"
+                             "s_mov_b64 exec, 1\n\t"
+                             "ds_add_rtn_u32 %0, %2, %3\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "s_mov_b64 exec, %1"
+                             : "=&v"(got), "=&s"(save)
+                             : "v"(n_pass_lds), "v"(add)
+                             : "memory");
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                const uint32_t ia = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+                const uint32_t ib = base + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+                if(pass_a && ia < kPassCap) // (a list that overflows is not used: n_pass > kPassCap sends phase C over all candidates)
+                    plist[ia] = (uint16_t)ca;
+                if(pass_b && ib < kPassCap)
+                    plist[ib] = (uint16_t)cb;
+            }
         }
         __syncthreads();
 
-        // ---- C. 3x3 strict non-max suppression over the listed pixels -> bitmap
-        for(uint32_t i = tid; i < n; i += 256)
+        // ---- C. 3x3 strict non-max suppression over the passing pixels -> bitmap
+        const uint32_t np = n_pass;
+        const bool short_list = np <= kPassCap;
+        for(uint32_t i = tid; i < (short_list ? np : n); i += 256)
         {
-            const uint32_t cxy = cand[i];
+            const uint32_t cxy = short_list ? plist[i] : cand[i];
             const int cy = (int)(cxy >> 8), cx = (int)(cxy & 0xFF);
             const uint8_t* q = &sc[(cy - 2) * kScP + (cx - 2)];
             const int s = q[0];
@@ -306,7 +344,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
             if(lane == 0)
+            {
                 n_cand = total != 0 ? 0xFFFFFFFFu : 0u; // tells the other waves whether to run the fallback pass
+                n_pass = 0;
+            }
         }
         __syncthreads();
         const bool done = n_cand != 0;

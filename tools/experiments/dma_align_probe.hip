@@ -15,8 +15,12 @@ __global__ __launch_bounds__(64) void probe(const uint8_t* __restrict__ src, int
     for(int i = lane; i < 64 * 16 / 4; i += 64)
         reinterpret_cast<uint32_t*>(tile)[i] = 0xEEEEEEEEu;
     __syncthreads();
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + shift + BYTES * lane),
-                                     (__attribute__((address_space(3))) void*)&tile[0], BYTES, 0, 0);
+    if constexpr(BYTES == 16)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + shift + 16 * lane),
+                                         (__attribute__((address_space(3))) void*)&tile[0], 16, 0, 0);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + shift + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)&tile[0], 4, 0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
     for(int i = lane; i < 64 * BYTES; i += 64)
