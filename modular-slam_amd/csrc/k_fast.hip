@@ -18,6 +18,7 @@
 //      and set one bit in a 64x64 bitmap; row popcounts of the bitmap give the reference's row-major
 //      output order with no dependence on atomic ordering.
 // If the cell is empty at the first threshold the same three steps run again with the fallback one.
+#include <type_traits>
 #include "common.hpp"
 #include "arc_score.hpp"
 
@@ -27,6 +28,22 @@ namespace mslam
 constexpr int kTileP = 80; // tile row pitch in bytes: five 16-byte LDS-DMA chunks from column x0 - 1 on,
 constexpr int kTileX = 1;  // i.e. tile byte = column + 1: the tested columns 3+4i .. 6+4i are bytes 4+4i .. 7+4i, dword i + 1
 constexpr int kScP = 68;   // score-map row pitch
+
+// A cell descriptor through the scalar unit (the compiler takes a vector load + v_readfirstlane per field for it).
+__device__ __forceinline__ CellDesc load_cell(const CellDesc* __restrict__ cells, int cell)
+{
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t r;
+    const uint32_t off = (uint32_t)cell * (uint32_t)sizeof(CellDesc);
+    asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(cells), "s"(off));
+    CellDesc c;
+    c.level = (int16_t)(r.x & 0xFFFFu), c.cw = (int16_t)(r.x >> 16);
+    c.ch = (int16_t)(r.y & 0xFFFFu), c.pad = 0;
+    c.x0 = (int16_t)(r.z & 0xFFFFu), c.y0 = (int16_t)(r.z >> 16);
+    c.ox = (int16_t)(r.w & 0xFFFFu), c.oy = (int16_t)(r.w >> 16);
+    return c;
+}
+static_assert(sizeof(CellDesc) == 16, "load_cell reads a descriptor as four dwords");
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -50,13 +67,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // 128-byte lines (a 70-byte cell row straddles two of them, its neighbours use the rest).  With cells of one
     // frame spread over all XCDs every L2 fetched those lines again — 2.7x the level's bytes at the memory side
     // (profiles/r02_a_pmc_fetch_write_per_launch.json); all cells of a frame now get ids with the same (id & 7).
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int f_local = (slot / g.n_cells) * 8 + xcd;
+    // (grid: x = cell * 8 + XCD, y = group of 8 frames — the XCD of a workgroup follows its linear id, and gridDim.x is a
+    // multiple of 8; no division, and the cell's descriptor comes through the scalar unit)
+    const int xcd = blockIdx.x & 7, cell_id = (int)(blockIdx.x >> 3);
+    const int f_local = (int)blockIdx.y * 8 + xcd;
     if(f_local >= n_frames)
         return;
-    const int cell_id = slot % g.n_cells;
     const size_t frame = (size_t)f_local + g.frame0;
-    const CellDesc c = cells[cell_id];
+    const CellDesc c = load_cell(cells, cell_id);
     const LevelGeom& lv = g.lv[c.level];
     const int cw = c.cw, ch = c.ch;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,8 +96,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if(t < n_chunks)
             {
                 const int r = (t * 13108) >> 16, j = t - r * 5; // t / 5 for t < 16384
+                const uint32_t off = (uint32_t)(r * lv.pitch + 16 * j); // (32-bit lane offset on a scalar base: no 64-bit vector adds)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + (size_t)r * lv.pitch + 16 * j),
+                    (const __attribute__((address_space(1))) void*)(src + off),
                     (__attribute__((address_space(3))) void*)&tile[(p * 256 + wave * 64) * 16], 16, 0, 0);
             }
         }
@@ -148,34 +167,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             uint32_t row = tile_lds + (uint32_t)((y - 3) * kTileP + 4 * i4); // byte offset of dword i4 of tile row y - 3 (the topmost row a step reads)
             uint32_t yx = (uint32_t)((y << 8) | xl);
             uint32_t n_grp = 0; // (wave-uniform)
+            // CHECKED = false: a full cell (every lane has four tested columns, every step four full rows — the interior cells,
+            // most of them): no per-row / per-lane validity test, no row counter
+            auto steps = [&](auto checked) {
+                constexpr bool CHECKED = decltype(checked)::value;
 #pragma unroll 1
-            for(int st = wv; st < n_steps; st += 4, y += 4 * rps, row += (uint32_t)(4 * rps * kTileP), yx += (uint32_t)(4 * rps) << 8)
-            {
-                uint32_t keep = 0;
-                if(colmask != 0 && y < ch - 3)
+                for(int st = wv; st < n_steps; st += 4, y += CHECKED ? 4 * rps : 0, row += (uint32_t)(4 * rps * kTileP), yx += (uint32_t)(4 * rps) << 8)
                 {
-                    // the four tested pixels are dword i + 1 of the row
-                    const lds32_t r = (lds32_t)row;
-                    const uint32_t d0 = r[60], d1 = r[61], d2 = r[62];
-                    const uint32_t nC = ~d1, U = r[1], D = r[121];
-                    const uint32_t Lf = __builtin_amdgcn_alignbyte(d1, d0, 1); // columns x-3 of the four pixels
-                    const uint32_t Rt = __builtin_amdgcn_alignbyte(d2, d1, 3); // columns x+3
-                    const uint32_t q0 = __builtin_amdgcn_lerp(D, nC, 0u), q8 = __builtin_amdgcn_lerp(U, nC, 0u);
-                    const uint32_t q4 = __builtin_amdgcn_lerp(Rt, nC, 0u), q12 = __builtin_amdgcn_lerp(Lf, nC, 0u);
-                    // brighter: (p0 or p8) and (p4 or p12);  not darker: (n0 and n8) or (n4 and n12) with n = "not darker"
-                    const uint32_t br = (__builtin_amdgcn_lerp(q0, kb, 0u) | __builtin_amdgcn_lerp(q8, kb, 0u)) &
-                                        (__builtin_amdgcn_lerp(q4, kb, 0u) | __builtin_amdgcn_lerp(q12, kb, 0u));
-                    const uint32_t nd = (__builtin_amdgcn_lerp(q0, kd, 0u) & __builtin_amdgcn_lerp(q8, kd, 0u)) |
-                                        (__builtin_amdgcn_lerp(q4, kd, 0u) & __builtin_amdgcn_lerp(q12, kd, 0u));
-                    keep = (br | ~nd) & colmask;
+                    uint32_t keep = 0;
+                    if(!CHECKED || (colmask != 0 && y < ch - 3))
+                    {
+                        // the four tested pixels are dword i + 1 of the row
+                        const lds32_t r = (lds32_t)row;
+                        const uint32_t d0 = r[60], d1 = r[61], d2 = r[62];
+                        const uint32_t nC = ~d1, U = r[1], D = r[121];
+                        const uint32_t Lf = __builtin_amdgcn_alignbyte(d1, d0, 1); // columns x-3 of the four pixels
+                        const uint32_t Rt = __builtin_amdgcn_alignbyte(d2, d1, 3); // columns x+3
+                        const uint32_t q0 = __builtin_amdgcn_lerp(D, nC, 0u), q8 = __builtin_amdgcn_lerp(U, nC, 0u);
+                        const uint32_t q4 = __builtin_amdgcn_lerp(Rt, nC, 0u), q12 = __builtin_amdgcn_lerp(Lf, nC, 0u);
+                        // brighter: (p0 or p8) and (p4 or p12);  not darker: (n0 and n8) or (n4 and n12) with n = "not darker"
+                        const uint32_t br = (__builtin_amdgcn_lerp(q0, kb, 0u) | __builtin_amdgcn_lerp(q8, kb, 0u)) &
+                                            (__builtin_amdgcn_lerp(q4, kb, 0u) | __builtin_amdgcn_lerp(q12, kb, 0u));
+                        const uint32_t nd = (__builtin_amdgcn_lerp(q0, kd, 0u) & __builtin_amdgcn_lerp(q8, kd, 0u)) |
+                                            (__builtin_amdgcn_lerp(q4, kd, 0u) & __builtin_amdgcn_lerp(q12, kd, 0u));
+                        keep = (br | ~nd) & (CHECKED ? colmask : 0x80808080u);
+                    }
+                    const bool any = keep != 0;
+                    const unsigned long long vote = __ballot(any);
+                    if(any)
+                        ((lds32_t)seg_lds)[n_grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u))] =
+                            keep | yx;
+                    n_grp += (uint32_t)__popcll(vote);
                 }
-                const bool any = keep != 0;
-                const unsigned long long vote = __ballot(any);
-                if(any)
-                    ((lds32_t)seg_lds)[n_grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u))] =
-                        keep | yx;
-                n_grp += (uint32_t)__popcll(vote);
-            }
+            };
+            if(cw == 70 && ch == 70)
+                steps(std::false_type{});
+            else
+                steps(std::true_type{});
             // expansion of the wave's records: pixel k of a record goes to the list slot given by the ballot of flag k
             for(uint32_t i0 = 0; i0 < n_grp; i0 += 64)
             {
@@ -202,18 +230,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
                 }
                 const uint32_t v = rec & 0x7F7Fu;
-                const lds16_t L = (lds16_t)cand_lds;
+                // (byte addresses, the wave-uniform part of each in a scalar: one v_lshl_add per store address)
+                uint32_t b2 = cand_lds + 2u * base;
                 if(f0)
-                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint16_t)v;
-                base += c0;
+                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)v;
+                b2 += 2u * c0;
                 if(f1)
-                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint16_t)(v + 1);
-                base += c1;
+                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)(v + 1);
+                b2 += 2u * c1;
                 if(f2)
-                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u))] = (uint16_t)(v + 2);
-                base += c2;
+                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u))) = (uint16_t)(v + 2);
+                b2 += 2u * c2;
                 if(f3)
-                    L[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, 0u))] = (uint16_t)(v + 3);
+                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, 0u))) = (uint16_t)(v + 3);
             }
             // the segment's storage becomes score map again (bytes beyond the four segments were cleared at the start)
             {
@@ -363,10 +392,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
                  uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s)
 {
-    const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)g.n_cells;
+    const dim3 grid(8u * (unsigned)g.n_cells, (unsigned)((n_frames + 7) / 8));
     Geometry gg = g;
     gg.frame0 = frame0;
-    hipLaunchKernelGGL(k_fast_cells, dim3(grid), dim3(256), 0, s, d_pyr, gg, d_cells, d_cell_cnt, d_cell_kp, ini_thr, min_thr,
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, d_pyr, gg, d_cells, d_cell_cnt, d_cell_kp, ini_thr, min_thr,
                        n_frames);
 }
 
