@@ -68,7 +68,7 @@ def stage_of_kernel(name):
         if name.startswith(pre):
             return st
     return None
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_per_step.json")  # tools/summarize_counters.py
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_per_step.json")  # tools/summarize_counters.py
 K2000_MIN_AREA = 984   # 640x480: 1986 keypoints per frame on the synthetic stream (1000, the reference default: ~1890)
 CFG4_MIN_AREA = 6340   # 1280x720, 8 levels: ~2015 keypoints per frame
 CLOCK_HZ = 2.4e9  # MI355X max shader clock (MI355X_MICROARCH.md); the vector-ALU issue figures are quoted at this clock
@@ -777,148 +777,173 @@ def main():
                         out["match_mfma_frac_alone"] = round(pairs * 512 / (alone["match_knn2"] * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS, 3)
                     return out
 
-                # cfg3: the same stream + DBoW3 loop scoring against a 1e6-word vocabulary every frame (k = 10, L = voc_levels)
-                voc = synth.make_vocabulary(10, a.voc_levels, seed=77)
-                ctx.bow_load(voc)
-                ctx.bow_db_reserve(32 * B)  # the leg adds 2 + 10 + 1 + 10 + 3 = 26 batches of entries: no storage doubling inside its timed steps
-                extras["cfg3"] = leg("cfg3", ctx, lambda i: step(i, bow=True), B, 10, counts_per_batch[0], cand_per_batch[0],
-                                     a.voc_levels,
-                                     "cfg3: the cfg2 step + DBoW3 transform (k=10, L=%d: %d words), tf-idf + L1 vectors, scores vs the "
-                                     "last 64 frames, inverted-file adds" % (a.voc_levels, 10 ** a.voc_levels))
-                # cfg2 at BASELINE.json's nominal K: the quadtree's stop area tuned so that a frame keeps 2000 +- 2 % keypoints
-                # (SURVEY.md §8d "min-area tuned so K ~ 2000"; the headline keeps the reference's default 1000 -> ~1880)
-                ts2 = torch.cuda.Stream()
-                ctx2 = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=K2000_MIN_AREA,
-                                   max_keypoints=4096 * k_scale, max_candidates=16384 * area, device=dev, stream=ts2.cuda_stream)
+                def guard(name, fn):
+                    """a leg that fails is recorded under <name>_error and the remaining legs still run"""
+                    try:
+                        fn()
+                    except Exception as e:  # noqa: BLE001
+                        extras[name + "_error"] = "%s: %s" % (type(e).__name__, e)
+                        torch.cuda.synchronize()
 
-                def step2(i):
-                    off2 = (i % n_batches) * B
-                    ctx2.detect_batch_dev(d_frames.data_ptr() + off2 * frame_bytes, B)
-                    ctx2.match_batch_dev(0.7, True)
-                    ctx2.backproject_batch_dev(d_depth.data_ptr() + off2 * depth_bytes)
-                step2(0)
-                ctx2.sync()
-                kp2 = int(pkg.read_device(ctx2, ctx2.batch_view().count, (B,), np.int32).sum())
-                cand2 = int(ctx2.debug_counts(pkg.DBG_CANDIDATES, B).sum())
-                extras["cfg2_k2000"] = leg("cfg2_k2000", ctx2, step2, B, 10, kp2, cand2, a.voc_levels,
-                                           "cfg2 with the quadtree stop area tuned to BASELINE.json's nominal 2000 keypoints per "
-                                           "frame (min-area %d instead of the reference default 1000), otherwise the headline step" %
-                                           K2000_MIN_AREA)
-                ctx2.close()
+                voc = synth.make_vocabulary(10, a.voc_levels, seed=77)  # cfg3 and cfg4
 
-                # cfg4, ONE rank of it: a 1280x720 stream, 8 levels, ~2000 keypoints per frame, the cfg3 BoW step and the device
-                # side of the cross-stream exchange (pack -> the world-1 "all-gather" = a device copy -> cross scores)
-                W4, H4, B4 = 1280, 720, 250
-                f4 = synth.make_stream(B4, W4, H4, seed=1234)
-                d4 = torch.from_numpy(f4).cuda()
-                dd4 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W4, H4, seed=1234)[0]] * B4)).view(np.int16)).cuda()
-                area4 = -(-W4 * H4 // (640 * 480))
-                ts4 = torch.cuda.Stream()
-                ctx4 = pkg.Context(width=W4, height=H4, max_batch=B4, n_levels=8, min_node_area=CFG4_MIN_AREA,
-                                   max_keypoints=4096 * area4, max_candidates=16384 * area4, device=dev, stream=ts4.cuda_stream)
-                ctx4.bow_load(voc)
-                ctx4.bow_db_reserve(32 * B4)
-                cross4 = CrossStreamLoopCandidates(k_max=2048)
+                def _leg_cfg3():
+                    # cfg3: the same stream + DBoW3 loop scoring against a 1e6-word vocabulary every frame (k = 10, L = voc_levels)
+                    ctx.bow_load(voc)
+                    ctx.bow_db_reserve(32 * B)  # the leg adds 2 + 10 + 1 + 10 + 3 = 26 batches of entries: no storage doubling inside its timed steps
+                    extras["cfg3"] = leg("cfg3", ctx, lambda i: step(i, bow=True), B, 10, counts_per_batch[0], cand_per_batch[0],
+                                         a.voc_levels,
+                                         "cfg3: the cfg2 step + DBoW3 transform (k=10, L=%d: %d words), tf-idf + L1 vectors, scores vs the "
+                                         "last 64 frames, inverted-file adds" % (a.voc_levels, 10 ** a.voc_levels))
+                guard('cfg3', _leg_cfg3)
 
-                def step4(i):
-                    ctx4.detect_batch_dev(d4.data_ptr(), B4)
-                    ctx4.match_batch_dev(0.7, True)
-                    ctx4.backproject_batch_dev(dd4.data_ptr())
-                    ctx4.bow_batch_dev(True)
-                    cross4.step_gpu(ctx4, ts4, B4)
-                step4(0)
-                cross4.finish(ts4)
-                ctx4.sync()
-                kp4 = int(pkg.read_device(ctx4, ctx4.batch_view().count, (B4,), np.int32).sum())
-                cand4 = int(ctx4.debug_counts(pkg.DBG_CANDIDATES, B4).sum())
-                c4 = cross4.collectives
-                l4 = leg("cfg4_one_rank", ctx4, step4, B4, 10, kp4, cand4, a.voc_levels,
-                         "cfg4, one rank: synthetic 1280x720 RGB-D stream (%d distinct frames), 8 levels, min-area %d, extract + match + "
-                         "back-projection + DBoW3 (k=10, L=%d) vectors / scores / inverted-file adds + exchange (pack, world-1 gather, "
-                         "cross-stream scores)" % (B4, CFG4_MIN_AREA, a.voc_levels))
-                cross4.finish(ts4)
-                n_coll = cross4.collectives - c4
-                # the exchange alone: pack + gather + cross score of one batch, on the streams the step uses
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(10):
-                    cross4.step_gpu(ctx4, ts4, B4)
-                cross4.finish(ts4)
-                torch.cuda.synchronize()
-                l4["exchange"] = {"bytes_per_collective": 4 * set_dwords(B4, cross4.k_max), "k_max": cross4.k_max,
-                                  "collectives_per_step": 1.0 if n_coll else 0.0,
-                                  "ms_per_batch_alone": (time.perf_counter() - t0) / 10 * 1e3,
-                                  "what": "mslam_hip_bow_pack_dev -> all_gather_into_tensor (world 1: a device copy of the set) -> "
-                                          "mslam_hip_bow_cross_score_packed_dev on the communication stream"}
-                extras["cfg4_one_rank"] = l4
-                ctx4.close()
-                del d4, dd4, f4, voc
-                # cfg5: 1920x1080, 3 levels, ~10 k keypoints per frame, k = 2 matcher with ratio test (64 M+ distances per frame)
-                W5, H5, B5 = 1920, 1080, 64
-                f5 = synth.make_stream(B5, W5, H5, seed=4321)
-                d5 = torch.from_numpy(f5).cuda()
-                dd5 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W5, H5, seed=4321)[0]] * B5)).view(np.int16)).cuda()
-                area5 = -(-W5 * H5 // (640 * 480))
-                ks5 = area5 * max(1, 1000 // 370)
-                ts5 = torch.cuda.Stream()
-                ctx5 = pkg.Context(width=W5, height=H5, max_batch=B5, n_levels=3, min_node_area=370,
-                                   max_keypoints=min(32736, 4096 * ks5), max_candidates=16384 * area5, device=dev,
-                                   stream=ts5.cuda_stream)
+                def _leg_cfg2_k2000():
+                    # cfg2 at BASELINE.json's nominal K: the quadtree's stop area tuned so that a frame keeps 2000 +- 2 % keypoints
+                    # (SURVEY.md §8d "min-area tuned so K ~ 2000"; the headline keeps the reference's default 1000 -> ~1880)
+                    ts2 = torch.cuda.Stream()
+                    ctx2 = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=K2000_MIN_AREA,
+                                       max_keypoints=4096 * k_scale, max_candidates=16384 * area, device=dev, stream=ts2.cuda_stream)
 
-                def step5(i):
-                    ctx5.detect_batch_dev(d5.data_ptr(), B5)
-                    ctx5.match_batch_dev(0.7, True)
-                    ctx5.backproject_batch_dev(dd5.data_ptr())
-                step5(0)
-                ctx5.sync()
-                kp5 = int(pkg.read_device(ctx5, ctx5.batch_view().count, (B5,), np.int32).sum())
-                cand5 = int(ctx5.debug_counts(pkg.DBG_CANDIDATES, B5).sum())
-                extras["cfg5"] = leg("cfg5", ctx5, step5, B5, 10, kp5, cand5, a.voc_levels,
-                                     "cfg5: synthetic 1920x1080 RGB-D stream (%d distinct frames), 3-level pyramid, min-area 370, "
-                                     "extract + knn-2 ratio-test matcher vs previous frame + back-projection" % B5)
-                ctx5.close()
-                del d5, dd5, f5
+                    def step2(i):
+                        off2 = (i % n_batches) * B
+                        ctx2.detect_batch_dev(d_frames.data_ptr() + off2 * frame_bytes, B)
+                        ctx2.match_batch_dev(0.7, True)
+                        ctx2.backproject_batch_dev(d_depth.data_ptr() + off2 * depth_bytes)
+                    step2(0)
+                    ctx2.sync()
+                    kp2 = int(pkg.read_device(ctx2, ctx2.batch_view().count, (B,), np.int32).sum())
+                    cand2 = int(ctx2.debug_counts(pkg.DBG_CANDIDATES, B).sum())
+                    extras["cfg2_k2000"] = leg("cfg2_k2000", ctx2, step2, B, 10, kp2, cand2, a.voc_levels,
+                                               "cfg2 with the quadtree stop area tuned to BASELINE.json's nominal 2000 keypoints per "
+                                               "frame (min-area %d instead of the reference default 1000), otherwise the headline step" %
+                                               K2000_MIN_AREA)
+                    ctx2.close()
 
-                # ---- what the reference's caller sees: ONE frame per call through the synchronous C-ABI entry points
-                # (rgbd_feature_frontend.cpp:187 detect, :237 match): host frame in, host arrays out
-                import ctypes as C
-                c1 = pkg.Context(width=a.width, height=a.height, max_batch=1, n_levels=a.levels, min_node_area=a.min_area, device=dev)
-                L = c1.L
-                K1 = c1.params.max_keypoints
-                xy = np.empty((K1, 2), np.float32)
-                de = np.empty((2, K1, 32), np.uint8)
-                oc = np.empty(K1, np.int32)
-                an = np.empty(K1, np.float32)
-                rs = np.empty(K1, np.float32)
-                fi = np.empty(K1, np.int32)
-                ti = np.empty(K1, np.int32)
-                n = C.c_int(0)
-                m = C.c_int(0)
-                pp = lambda x: x.ctypes.data_as(C.c_void_p)
-                t_det, t_mat, counts = [], [], [0, 0]
-                for i in range(220):
-                    fr = frames[i % 16]
+                guard('cfg2_k2000', _leg_cfg2_k2000)
+
+                def _leg_cfg4_one_rank():
+                    # cfg4, ONE rank of it: a 1280x720 stream, 8 levels, ~2000 keypoints per frame, the cfg3 BoW step and the device
+                    # side of the cross-stream exchange (pack -> the world-1 "all-gather" = a device copy -> cross scores)
+                    W4, H4, B4 = 1280, 720, 250
+                    f4 = synth.make_stream(B4, W4, H4, seed=1234)
+                    d4 = torch.from_numpy(f4).cuda()
+                    dd4 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W4, H4, seed=1234)[0]] * B4)).view(np.int16)).cuda()
+                    area4 = -(-W4 * H4 // (640 * 480))
+                    ts4 = torch.cuda.Stream()
+                    ctx4 = pkg.Context(width=W4, height=H4, max_batch=B4, n_levels=8, min_node_area=CFG4_MIN_AREA,
+                                       max_keypoints=min(8192, 4096 * area4),  # (the BoW scoring kernel keeps a frame's vector in LDS: <= 8192 keypoints)
+                                       max_candidates=16384 * area4, device=dev, stream=ts4.cuda_stream)
+                    ctx4.bow_load(voc)
+                    ctx4.bow_db_reserve(32 * B4)
+                    cross4 = CrossStreamLoopCandidates(k_max=2048)
+
+                    def step4(i):
+                        ctx4.detect_batch_dev(d4.data_ptr(), B4)
+                        ctx4.match_batch_dev(0.7, True)
+                        ctx4.backproject_batch_dev(dd4.data_ptr())
+                        ctx4.bow_batch_dev(True)
+                        cross4.step_gpu(ctx4, ts4, B4)
+                    step4(0)
+                    cross4.finish(ts4)
+                    ctx4.sync()
+                    kp4 = int(pkg.read_device(ctx4, ctx4.batch_view().count, (B4,), np.int32).sum())
+                    cand4 = int(ctx4.debug_counts(pkg.DBG_CANDIDATES, B4).sum())
+                    c4 = cross4.collectives
+                    l4 = leg("cfg4_one_rank", ctx4, step4, B4, 10, kp4, cand4, a.voc_levels,
+                             "cfg4, one rank: synthetic 1280x720 RGB-D stream (%d distinct frames), 8 levels, min-area %d, extract + match + "
+                             "back-projection + DBoW3 (k=10, L=%d) vectors / scores / inverted-file adds + exchange (pack, world-1 gather, "
+                             "cross-stream scores)" % (B4, CFG4_MIN_AREA, a.voc_levels))
+                    cross4.finish(ts4)
+                    n_coll = cross4.collectives - c4
+                    # the exchange alone: pack + gather + cross score of one batch, on the streams the step uses
+                    torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    rc = L.mslam_hip_detect(c1._h, pp(fr), a.width, a.height, K1, pp(xy), pp(de[i & 1]), pp(oc), pp(an), pp(rs), C.byref(n))
-                    t1 = time.perf_counter()
-                    counts[i & 1] = n.value
-                    if rc == 0 and i > 0:
-                        rc = L.mslam_hip_match(c1._h, pp(de[i & 1]), counts[i & 1], pp(de[(i & 1) ^ 1]), counts[(i & 1) ^ 1],
-                                               C.c_double(0.7), pp(fi), pp(ti), C.byref(m))
-                    t2 = time.perf_counter()
-                    if rc != 0:
-                        raise RuntimeError("single-frame call failed: %d" % rc)
-                    if i >= 20:
-                        t_det.append(t1 - t0)
-                        t_mat.append(t2 - t1)
-                c1.close()
-                extras["latency_us"] = {
-                    "detect": round(float(np.median(t_det)) * 1e6, 1), "match": round(float(np.median(t_mat)) * 1e6, 1),
-                    "detect_p95": round(float(np.percentile(t_det, 95)) * 1e6, 1),
-                    "match_p95": round(float(np.percentile(t_mat, 95)) * 1e6, 1),
-                    "what": "median over 200 synchronous single-frame calls through the C ABI (mslam_hip_detect / mslam_hip_match: "
-                            "host frame in, host keypoints / descriptors / matches out, %d keypoints per frame), what "
-                            "IFeatureDetector::detect / IFeatureMatcher::match of the plugin cost per call" % counts[0]}
+                    for i in range(10):
+                        cross4.step_gpu(ctx4, ts4, B4)
+                    cross4.finish(ts4)
+                    torch.cuda.synchronize()
+                    l4["exchange"] = {"bytes_per_collective": 4 * set_dwords(B4, cross4.k_max), "k_max": cross4.k_max,
+                                      "collectives_per_step": 1.0 if n_coll else 0.0,
+                                      "ms_per_batch_alone": (time.perf_counter() - t0) / 10 * 1e3,
+                                      "what": "mslam_hip_bow_pack_dev -> all_gather_into_tensor (world 1: a device copy of the set) -> "
+                                              "mslam_hip_bow_cross_score_packed_dev on the communication stream"}
+                    extras["cfg4_one_rank"] = l4
+                    ctx4.close()
+                    del d4, dd4, f4
+                guard('cfg4_one_rank', _leg_cfg4_one_rank)
+
+                def _leg_cfg5():
+                    # cfg5: 1920x1080, 3 levels, ~10 k keypoints per frame, k = 2 matcher with ratio test (64 M+ distances per frame)
+                    W5, H5, B5 = 1920, 1080, 64
+                    f5 = synth.make_stream(B5, W5, H5, seed=4321)
+                    d5 = torch.from_numpy(f5).cuda()
+                    dd5 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W5, H5, seed=4321)[0]] * B5)).view(np.int16)).cuda()
+                    area5 = -(-W5 * H5 // (640 * 480))
+                    ks5 = area5 * max(1, 1000 // 370)
+                    ts5 = torch.cuda.Stream()
+                    ctx5 = pkg.Context(width=W5, height=H5, max_batch=B5, n_levels=3, min_node_area=370,
+                                       max_keypoints=min(32736, 4096 * ks5), max_candidates=16384 * area5, device=dev,
+                                       stream=ts5.cuda_stream)
+
+                    def step5(i):
+                        ctx5.detect_batch_dev(d5.data_ptr(), B5)
+                        ctx5.match_batch_dev(0.7, True)
+                        ctx5.backproject_batch_dev(dd5.data_ptr())
+                    step5(0)
+                    ctx5.sync()
+                    kp5 = int(pkg.read_device(ctx5, ctx5.batch_view().count, (B5,), np.int32).sum())
+                    cand5 = int(ctx5.debug_counts(pkg.DBG_CANDIDATES, B5).sum())
+                    extras["cfg5"] = leg("cfg5", ctx5, step5, B5, 10, kp5, cand5, a.voc_levels,
+                                         "cfg5: synthetic 1920x1080 RGB-D stream (%d distinct frames), 3-level pyramid, min-area 370, "
+                                         "extract + knn-2 ratio-test matcher vs previous frame + back-projection" % B5)
+                    ctx5.close()
+                    del d5, dd5, f5
+
+                guard('cfg5', _leg_cfg5)
+
+                def _leg_latency_us():
+                    # ---- what the reference's caller sees: ONE frame per call through the synchronous C-ABI entry points
+                    # (rgbd_feature_frontend.cpp:187 detect, :237 match): host frame in, host arrays out
+                    import ctypes as C
+                    c1 = pkg.Context(width=a.width, height=a.height, max_batch=1, n_levels=a.levels, min_node_area=a.min_area, device=dev)
+                    L = c1.L
+                    K1 = c1.params.max_keypoints
+                    xy = np.empty((K1, 2), np.float32)
+                    de = np.empty((2, K1, 32), np.uint8)
+                    oc = np.empty(K1, np.int32)
+                    an = np.empty(K1, np.float32)
+                    rs = np.empty(K1, np.float32)
+                    fi = np.empty(K1, np.int32)
+                    ti = np.empty(K1, np.int32)
+                    n = C.c_int(0)
+                    m = C.c_int(0)
+                    pp = lambda x: x.ctypes.data_as(C.c_void_p)
+                    t_det, t_mat, counts = [], [], [0, 0]
+                    for i in range(220):
+                        fr = frames[i % 16]
+                        t0 = time.perf_counter()
+                        rc = L.mslam_hip_detect(c1._h, pp(fr), a.width, a.height, K1, pp(xy), pp(de[i & 1]), pp(oc), pp(an), pp(rs), C.byref(n))
+                        t1 = time.perf_counter()
+                        counts[i & 1] = n.value
+                        if rc == 0 and i > 0:
+                            rc = L.mslam_hip_match(c1._h, pp(de[i & 1]), counts[i & 1], pp(de[(i & 1) ^ 1]), counts[(i & 1) ^ 1],
+                                                   C.c_double(0.7), pp(fi), pp(ti), C.byref(m))
+                        t2 = time.perf_counter()
+                        if rc != 0:
+                            raise RuntimeError("single-frame call failed: %d" % rc)
+                        if i >= 20:
+                            t_det.append(t1 - t0)
+                            t_mat.append(t2 - t1)
+                    c1.close()
+                    extras["latency_us"] = {
+                        "detect": round(float(np.median(t_det)) * 1e6, 1), "match": round(float(np.median(t_mat)) * 1e6, 1),
+                        "detect_p95": round(float(np.percentile(t_det, 95)) * 1e6, 1),
+                        "match_p95": round(float(np.percentile(t_mat, 95)) * 1e6, 1),
+                        "what": "median over 200 synchronous single-frame calls through the C ABI (mslam_hip_detect / mslam_hip_match: "
+                                "host frame in, host keypoints / descriptors / matches out, %d keypoints per frame), what "
+                                "IFeatureDetector::detect / IFeatureMatcher::match of the plugin cost per call" % counts[0]}
+                guard('latency_us', _leg_latency_us)
+
     except Exception as e:  # noqa: BLE001 - any failure of an extra leg must not cost the headline
         extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
 

@@ -278,12 +278,17 @@ int mslam_hip_get_points_view(mslam_hip_ctx* ctx, mslam_hip_points_view* view);
  * use_extrinsic_guess is non-zero, and the result on output; inliers (n bytes, may be NULL) is the consensus mask of
  * the best hypothesis.  Returns MSLAM_HIP_E_NO_MODEL when no hypothesis reaches 4 inliers (solvePnPRansac == false).
  * The minimal solver, sampling and refinement are this library's own (P3P, splitmix64 with `seed`, damped
- * Gauss-Newton): see csrc/k_pnp.hip for what is and is not the same as OpenCV's internals.  The confidence bound only
- * ends OpenCV's loop early; here all `iterations` hypotheses are scored in one launch. */
+ * Gauss-Newton): see csrc/k_pnp.hip for what is and is not the same as OpenCV's internals.  The call site's confidence
+ * (0.99, :57) ends the loop as in OpenCV's RANSACPointSetRegistrator: every new best hypothesis lowers the iteration
+ * count to log(1 - confidence) / log(1 - w^4) (w = its inlier share), hypotheses beyond it are not looked at. */
 int mslam_hip_pnp_ransac(mslam_hip_ctx* ctx, const float* object_points, const float* image_points, int n, double fx,
                          double fy, double cx, double cy, int use_extrinsic_guess, int iterations,
                          double reprojection_error, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers,
                          int* n_inliers);
+
+/* The RANSAC confidence of both PnP entry points (default 0.99 = the reference's call, cv_ransac_pnp.cpp:57); a value
+ * outside (0, 1) switches the early exit off: all `iterations` hypotheses are scored. */
+int mslam_hip_pnp_set_confidence(mslam_hip_ctx* ctx, double confidence);
 
 /* Batched device form (the frame-to-frame tracking step of the RGB-D front end on device data): for every frame t >= 1 of
  * the last batch, the matches (frame t -> frame t-1) of mslam_hip_match_batch_dev whose train keypoint has a valid

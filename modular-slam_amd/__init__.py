@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "mslam_hip_last_match_kernel",
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
     "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size", "mslam_hip_qlz_decompress",
-    "mslam_hip_pnp_ransac", "mslam_hip_pnp_batch_dev", "mslam_hip_get_pnp_view",
+    "mslam_hip_pnp_ransac", "mslam_hip_pnp_batch_dev", "mslam_hip_get_pnp_view", "mslam_hip_pnp_set_confidence",
 ]
 
 
@@ -248,6 +248,10 @@ class Context:
         self._chk(self.L.mslam_hip_pnp_batch_dev(self._h, C.c_double(focal[0]), C.c_double(focal[1]), C.c_double(principal[0]),
                                                  C.c_double(principal[1]), int(iterations), C.c_double(reprojection_error),
                                                  C.c_uint64(seed)))
+
+    def pnp_set_confidence(self, confidence):
+        """RANSAC confidence of pnp_ransac / pnp_batch_dev (default 0.99, cv_ransac_pnp.cpp:57); outside (0, 1): no early exit"""
+        self._chk(self.L.mslam_hip_pnp_set_confidence(self._h, C.c_double(confidence)))
 
     def pnp_view(self):
         v = PnpView()

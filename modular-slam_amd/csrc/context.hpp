@@ -128,6 +128,7 @@ struct mslam_hip_ctx
     double *d_pnp_hyp = nullptr, *d_pnp_out = nullptr;
     uint8_t* d_pnp_mask = nullptr;
     int pnp_iterations = 0;
+    double pnp_confidence = 0.99; // cv_ransac_pnp.cpp:57 (mslam_hip_pnp_set_confidence)
     // single-problem PnP scratch (mslam_hip_pnp_ransac), grown on demand
     float *d_pnp1_obj = nullptr, *d_pnp1_img = nullptr;
     double *d_pnp1_hyp = nullptr, *d_pnp1_out = nullptr;

@@ -492,7 +492,7 @@ int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
     {
         // a handful of pairs (the synchronous single-frame calls): two query tiles per wave, twice as many waves —
         // the kernel's latency is what counts there (39 -> 13 us for one 1900 x 1900 pair), not its throughput
-        static const int skip_from = [] { const char* e = getenv("MSLAM_HIP_MATCH_SKIP_FROM"); return e ? atoi(e) : 6000; }();
+        const int skip_from = [] { const char* e = getenv("MSLAM_HIP_MATCH_SKIP_FROM"); return e ? atoi(e) : 6000; }(); // (read per launch: a test switches it)
         if(n_pairs <= 4)
             launch_fp4<2>(a, n_pairs, s);
         else if(max_train >= skip_from) // long scans (cfg5: 10 k train rows): most late blocks cannot change a top-2

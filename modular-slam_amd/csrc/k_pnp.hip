@@ -9,10 +9,14 @@
 // useExtrinsicGuess is set, and the inlier mask is that of the best hypothesis.
 // What differs from OpenCV's internals (not in the reference tree; parity with it is UNPINNED — DESIGN.md): the minimal
 // solver is P3P (Grunert's quartic, 3 points + 1 to disambiguate) instead of EPnP on 5 points, samples come from a
-// counter-based generator (splitmix64) instead of cv::RNG, all hypotheses are always evaluated (no early exit on the
-// confidence bound), and the refinement is a damped Gauss-Newton on (rotation, translation) instead of
-// cvFindExtrinsicCameraParams2's LM on (rvec, tvec).  tests/ pin it against ground-truth poses and an independent
-// numpy oracle.
+// counter-based generator (splitmix64) instead of cv::RNG, and the refinement is a damped Gauss-Newton on (rotation,
+// translation) instead of
+// cvFindExtrinsicCameraParams2's LM on (rvec, tvec).  The confidence of the call site (0.99, :57) is honoured the way
+// RANSACPointSetRegistrator::run does it: hypotheses are looked at in their order, every new best one lowers the
+// number of iterations to log(1 - confidence) / log(1 - w^m) (w = its inlier share, m = 4 sample points here; OpenCV's
+// RANSACUpdateNumIters, cvRound and all), and the loop ends there — the winner is the best of the hypotheses
+// 0 .. niters-1, exactly what the sequential loop returns.  tests/ pin it against ground-truth poses and an
+// independent numpy oracle.
 //
 // One workgroup solves one problem: hypotheses are generated one per thread, scored against every point by the
 // whole workgroup, and the refinement's normal equations are reduced in a fixed order (bit-reproducible).
@@ -37,6 +41,7 @@ struct PnpArgs
     double R0[9], t0[3]; // the caller's guess (use_guess)
     int use_guess;
     int iterations;
+    double confidence; // the RANSAC loop ends once enough hypotheses were looked at for this confidence (>= 1 or <= 0: never early)
     double thr2; // reprojectionError^2
     unsigned long long seed;
     double* hyp;     // [iterations][12] R (row major), t
@@ -253,6 +258,28 @@ __device__ bool p3p_hypothesis(const Cam& k, const V3* P, const double* uv, doub
     return found;
 }
 
+// OpenCV's RANSACUpdateNumIters(p, ep, modelPoints, maxIters) (calib3d/src/ptsetreg.cpp): the number of samples after which
+// an all-inlier sample has been drawn with probability p when a share ep of the points are outliers
+__device__ __forceinline__ int ransac_update_iters(double p, double ep, int model_points, int max_iters)
+{
+    if(!(p > 0.0) || !(p < 1.0))
+        return max_iters; // no early exit asked for
+    ep = fmax(ep, 0.0);
+    ep = fmin(ep, 1.0);
+    double num = fmax(1.0 - p, 2.2250738585072014e-308);
+    double w = 1.0 - ep, wm = 1.0;
+    for(int i = 0; i < model_points; ++i)
+        wm *= w; // pow(1 - ep, modelPoints) for a small integer exponent, in a fixed order
+    double denom = 1.0 - wm;
+    if(denom < 2.2250738585072014e-308)
+        return 0;
+    num = log(num);
+    denom = log(denom);
+    if(denom >= 0 || -num >= max_iters * (-denom))
+        return max_iters;
+    return (int)rint(num / denom); // cvRound
+}
+
 constexpr int kPnpThreads = 256;
 
 // fixed-order workgroup sum of `cnt` doubles per thread (acc[cnt]); the totals land in red[0..cnt).  Butterfly inside
@@ -295,7 +322,7 @@ __device__ __forceinline__ void wg_sum(double* acc, double* red, int tid)
 // one problem, one workgroup (shared by the single-problem kernel and the batched one)
 __device__ __forceinline__ void pnp_problem(const PnpArgs& a, double* red /* LDS [kPnpRed] doubles + [kPnpLdsPts][5] floats */)
 {
-    __shared__ int s_best, s_cnt;
+    __shared__ int s_best, s_cnt, s_niters;
     __shared__ double sR[9], st[3], sNew[12];
     __shared__ double s_lambda, s_cost;
     __shared__ int s_stop;
@@ -366,12 +393,20 @@ __device__ __forceinline__ void pnp_problem(const PnpArgs& a, double* red /* LDS
         pts[5 * i + 3] = a.img[2 * i], pts[5 * i + 4] = a.img[2 * i + 1];
     }
     __syncthreads();
+    // Rounds of one hypothesis per wave; after every round thread 0 walks the round's hypotheses in order, exactly as the
+    // sequential RANSAC loop would (a new best hypothesis lowers s_niters; a hypothesis at or beyond s_niters is never
+    // looked at), so a clean scene ends after a round or two instead of `iterations` hypotheses.
+    if(tid == 0)
+        s_best = -1, s_cnt = -1, s_niters = a.iterations;
+    __syncthreads();
     {
         const int lane = tid & 63, wave = tid >> 6;
-        for(int h = wave; h < a.iterations; h += kPnpThreads / 64)
+        constexpr int W = kPnpThreads / 64;
+        for(int h0 = 0; h0 < s_niters; h0 += W)
         {
-            if(counts[h] < 0)
-                continue;
+            const int h = h0 + wave;
+            if(h < a.iterations && counts[h] >= 0)
+            {
             // the hypothesis in registers (wave-uniform), the points from LDS when they fit
             double hp[12];
             for(int j = 0; j < 12; ++j)
@@ -401,19 +436,26 @@ __device__ __forceinline__ void pnp_problem(const PnpArgs& a, double* red /* LDS
                 c += __shfl_xor(c, o);
             if(lane == 0)
                 counts[h] = c;
+            }
+            __syncthreads();
+            if(tid == 0)
+            {
+                int best = s_best, bc = s_cnt, niters = s_niters;
+                for(int k = 0; k < W && h0 + k < niters; ++k)
+                {
+                    const int hh = h0 + k;
+                    // RANSACPointSetRegistrator::run: goodCount > max(maxGoodCount, modelPoints - 1)
+                    if(counts[hh] > max(bc, 3))
+                    {
+                        bc = counts[hh], best = hh;
+                        niters = ransac_update_iters(a.confidence, (double)(n - bc) / (double)n, 4, niters);
+                    }
+                }
+                s_best = best, s_cnt = bc, s_niters = niters;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
-    if(tid == 0)
-    {
-        int best = -1, bc = -1;
-        for(int h = 0; h < a.iterations; ++h)
-            if(counts[h] > bc)
-                bc = counts[h], best = h;
-        s_best = best;
-        s_cnt = bc;
-    }
-    __syncthreads();
     const int best = s_best;
     if(best < 0 || s_cnt < 4)
     {
@@ -850,6 +892,7 @@ extern "C" int mslam_hip_pnp_ransac(mslam_hip_ctx* c, const float* object_points
     a.t0[0] = tvec[0], a.t0[1] = tvec[1], a.t0[2] = tvec[2];
     a.iterations = iterations;
     a.thr2 = reprojection_error * reprojection_error;
+    a.confidence = c->pnp_confidence;
     a.seed = seed;
     a.hyp = d_hyp, a.counts = d_counts, a.mask = d_mask, a.out = d_out;
     const size_t lds = (size_t)kPnpRed * 8 + (size_t)kPnpLdsHyp * (96 + 4) + (size_t)kPnpLdsPts * 21;
@@ -943,6 +986,7 @@ extern "C" int mslam_hip_pnp_batch_dev(mslam_hip_ctx* c, double fx, double fy, d
     a.use_guess = 0;
     a.iterations = iterations;
     a.thr2 = reprojection_error * reprojection_error;
+    a.confidence = c->pnp_confidence;
     a.seed = seed;
     a.hyp = c->d_pnp_hyp, a.counts = c->d_pnp_counts, a.mask = c->d_pnp_mask, a.out = c->d_pnp_out;
     b.n = c->d_pnp_n;
@@ -974,5 +1018,15 @@ extern "C" int mslam_hip_get_pnp_view(mslam_hip_ctx* c, mslam_hip_pnp_view* v)
     v->object_points = c->d_pnp_obj;
     v->image_points = c->d_pnp_img;
     v->inliers = c->d_pnp_mask;
+    return MSLAM_HIP_OK;
+}
+
+extern "C" int mslam_hip_pnp_set_confidence(mslam_hip_ctx* c, double confidence)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(!(confidence == confidence))
+        return MSLAM_HIP_E_INVALID; // NaN
+    c->pnp_confidence = confidence;
     return MSLAM_HIP_OK;
 }

@@ -153,20 +153,42 @@ def refine(R, t, obj, img, cam, mask, iters=50):
     return R, t, c
 
 
-def pnp_ransac(obj, img, cam, iterations=100, thr=5.0, seed=0, guess=None):
-    """-> dict(R, t, mask, best, counts, hyps) or None.  cam = (fx, fy, cx, cy); guess = (R0, t0) or None."""
+def update_num_iters(p, ep, model_points, max_iters):
+    """OpenCV's RANSACUpdateNumIters (calib3d/src/ptsetreg.cpp): samples needed to have drawn an all-inlier one with
+    probability p when a share ep of the points are outliers; p outside (0, 1): no early exit"""
+    if not (0.0 < p < 1.0):
+        return max_iters
+    ep = min(max(ep, 0.0), 1.0)
+    num = max(1.0 - p, np.finfo(np.float64).tiny)
+    denom = 1.0 - (1.0 - ep) ** model_points
+    if denom < np.finfo(np.float64).tiny:
+        return 0
+    num, denom = np.log(num), np.log(denom)
+    if denom >= 0 or -num >= max_iters * (-denom):
+        return max_iters
+    return int(np.rint(num / denom))                  # cvRound
+
+
+def pnp_ransac(obj, img, cam, iterations=100, thr=5.0, seed=0, guess=None, confidence=0.99):
+    """-> dict(R, t, mask, best, counts, hyps, looked_at) or None.  cam = (fx, fy, cx, cy); guess = (R0, t0) or None.
+    The loop is RANSACPointSetRegistrator::run's: hypotheses in order, a new best one (more inliers than the best so far
+    and at least 4) lowers the iteration count for `confidence` (cv_ransac_pnp.cpp:57 passes 0.99)."""
     obj, img = np.asarray(obj, np.float32), np.asarray(img, np.float32)
     n = len(obj)
     hyps, counts = [], []
-    for h in range(iterations):
+    best, bc, niters, h = -1, -1, iterations, 0
+    while h < niters:
         idx = sample_indices(seed, h, n)
         hy = hypothesis(obj, img, cam, idx) if idx is not None else None
         hyps.append(hy)
         counts.append(-1 if hy is None else int(inliers_of(hy[0], hy[1], obj, img, cam, thr).sum()))
-    best = int(np.argmax(counts))                     # first maximum
-    if counts[best] < 4:
+        if counts[h] > max(bc, 3):
+            bc, best = counts[h], h
+            niters = update_num_iters(confidence, (n - bc) / n, 4, niters)
+        h += 1
+    if best < 0:
         return None
     mask = inliers_of(hyps[best][0], hyps[best][1], obj, img, cam, thr)
     R0, t0 = guess if guess is not None else hyps[best]
     R, t, c = refine(np.array(R0, np.float64), np.array(t0, np.float64), obj, img, cam, mask)
-    return dict(R=R, t=t, mask=mask, best=best, counts=counts, hyps=hyps, cost=c)
+    return dict(R=R, t=t, mask=mask, best=best, counts=counts, hyps=hyps, cost=c, looked_at=h)

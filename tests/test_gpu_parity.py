@@ -219,6 +219,41 @@ def test_batch_device_path(pkg, orc, synth_frames, matcher):
     c.close()
 
 
+@pytest.mark.parametrize("kcap,skip_env", [(8192, None), (4096, "0")])
+def test_batch_matcher_tile_skip_path(pkg, orc, synth_frames, monkeypatch, kcap, skip_env):
+    """k_match_knn2_fp4<4, SKIP = true> — more than four pairs and a train capacity of at least MSLAM_HIP_MATCH_SKIP_FROM
+    (6000) rows: a (train tile, query tile) block that cannot change any lane's top-2 skips its update, the owed ageing of the
+    keys is applied later.  Dense keypoint sets (min-area 60: ~4 k per frame, 125 train tiles per query) through the
+    batched path, against the oracle's matcher; the second case forces the skip path onto the K = 4096 batch shape."""
+    import torch
+    if skip_env is not None:
+        monkeypatch.setenv("MSLAM_HIP_MATCH_SKIP_FROM", skip_env)
+    area = 60 if kcap == 8192 else 1000
+    frames = synth_frames[:6]
+    dev = torch.from_numpy(frames).cuda()
+    c = pkg.Context(width=640, height=480, max_batch=6, max_keypoints=kcap, min_node_area=area)
+    c.detect_batch_dev(dev.data_ptr(), 6)
+    c.match_batch_dev(0.7, False)
+    c.sync()
+    assert c.last_match_kernel() == "matrix"
+    v = c.batch_view()
+    K = v.capacity
+    p = orc.params(min_size=area)
+    refs = [orc.detect(f, p) for f in frames]
+    cnt = pkg.read_device(c, v.count, (6,), np.int32)
+    mc = pkg.read_device(c, v.match_count, (6,), np.int32)
+    mf = pkg.read_device(c, v.match_from, (6, K), np.int32)
+    mt = pkg.read_device(c, v.match_to, (6, K), np.int32)
+    assert [int(x) for x in cnt] == [len(r["xy"]) for r in refs]
+    if kcap == 8192:
+        assert cnt.min() > 3500
+    assert mc[0] == 0
+    for t in range(1, 6):
+        rf, rt = orc.match(refs[t]["desc"], refs[t - 1]["desc"])
+        assert mc[t] == len(rf) and np.array_equal(mf[t, :mc[t]], rf) and np.array_equal(mt[t, :mc[t]], rt), t
+    c.close()
+
+
 def test_batch_matcher_auto_switch_on_capacity(pkg, orc, synth_frames):
     """MATCHER_AUTO on the batched path: a context whose max_keypoints exceeds the matrix-core kernel's train range
     (32 736 rows: the 14-bit age field of its sort key) must take the xor/popcount kernel (k_match.hip:

@@ -48,6 +48,25 @@ def test_oracle_recovers_ground_truth():
                          rng.uniform(0, 480, (50, 2)).astype(np.float32), CAM, thr=0.5) is None
 
 
+def test_oracle_confidence_bound_ends_clean_scenes_early():
+    """cv_ransac_pnp.cpp:57 passes confidence 0.99: RANSACUpdateNumIters on every new best hypothesis.  A clean scene needs a
+    handful of hypotheses, a 60 %-outlier scene (w^4 = 2.6 %: 178 samples for 0.99) runs all 100; without a confidence the
+    loop never ends early; and the winner is the first maximum of the hypotheses looked at."""
+    assert po.update_num_iters(0.99, 0.0, 4, 100) == 0 and po.update_num_iters(0.99, 0.6, 4, 100) == 100
+    assert po.update_num_iters(0.99, 0.1, 4, 100) == 4 and po.update_num_iters(0.99, 0.3, 4, 100) == 17
+    assert po.update_num_iters(1.0, 0.1, 4, 100) == 100 and po.update_num_iters(0.0, 0.1, 4, 100) == 100
+    obj, img, R, t, good = scene(21, outliers=0.0)
+    clean = po.pnp_ransac(obj, img, CAM, seed=2)
+    assert clean["looked_at"] <= 8 and rot_err(clean["R"], R) < 0.1
+    obj, img, R, t, good = scene(22, outliers=0.6)
+    hard = po.pnp_ransac(obj, img, CAM, seed=2)
+    assert hard["looked_at"] == 100 and rot_err(hard["R"], R) < 0.2
+    full = po.pnp_ransac(obj, img, CAM, seed=2, confidence=1.0)
+    assert full["looked_at"] == 100 and full["best"] == hard["best"]
+    c = hard["counts"]
+    assert hard["best"] == int(np.argmax(c)) and c[hard["best"]] >= 4
+
+
 def test_p3p_solutions_contain_the_true_pose():
     rng = np.random.default_rng(11)
     for _ in range(50):
@@ -78,6 +97,19 @@ def test_gpu_pnp_matches_ground_truth_and_oracle(pkg):
     ref = po.pnp_ransac(obj, img, CAM, seed=3, guess=(R0, t + 0.05))
     assert np.array_equal(mask, ref["mask"]) and rot_err(po.rodrigues(r), ref["R"]) < 1e-6
     assert np.linalg.norm(tv - ref["t"]) < 1e-7 and rot_err(po.rodrigues(r), R) < 0.1
+    # the confidence bound (cv_ransac_pnp.cpp:57): a clean scene stops after a few hypotheses, a 60 %-outlier scene does
+    # not; both agree with the oracle's sequential loop, and switching the bound off gives the all-hypotheses result
+    for sd, outl in ((21, 0.0), (22, 0.6), (23, 0.3)):
+        obj, img, R, t, good = scene(sd, outliers=outl)
+        ref = po.pnp_ransac(obj, img, CAM, seed=2)
+        r, tv, mask = c.pnp_ransac(obj, img, CAM[:2], CAM[2:], seed=2)
+        assert np.array_equal(mask, ref["mask"]) and rot_err(po.rodrigues(r), ref["R"]) < 1e-6, (sd, ref["looked_at"])
+        assert (ref["looked_at"] <= 8) == (outl == 0.0) and (ref["looked_at"] == 100) == (outl == 0.6)
+        c.pnp_set_confidence(1.0)
+        full = po.pnp_ransac(obj, img, CAM, seed=2, confidence=1.0)
+        r, tv, mask = c.pnp_ransac(obj, img, CAM[:2], CAM[2:], seed=2)
+        assert full["looked_at"] == 100 and np.array_equal(mask, full["mask"]) and rot_err(po.rodrigues(r), full["R"]) < 1e-6
+        c.pnp_set_confidence(0.99)
     # no model
     rng = np.random.default_rng(5)
     assert c.pnp_ransac(rng.normal(size=(50, 3)).astype(np.float32) + [0, 0, 5],
