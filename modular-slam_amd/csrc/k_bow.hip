@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256) void k_bow_commit(const uint32_t* __restrict__
 }
 
 constexpr int kScoreBlocksPerFrame = 2; // the query hash is rebuilt per block; two blocks per frame keep 2 blocks/CU busy
+constexpr uint32_t kIdxBits = 14, kIdxMask = (1u << kIdxBits) - 1u; // k_bow_score's table word: index + 1 (cap <= 16383) | Bloom field << 14
 constexpr int kScoreWaves = 16; // waves per workgroup; the workgroup owns one query frame, each wave a share of the entries
 
 // L1Scoring::score of query vector `qslot + blockIdx.y` against the window of database entries that
@@ -494,11 +495,27 @@ __global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
         qv[i] = v1[i];
     }
     __syncthreads();
+    // A slot holds the index (+ 1) of the query word stored there in its low 14 bits and, in bits 14 .. 29, a 16-bit Bloom
+    // field for the words whose HOME slot it is: a database word that is not in the query — most of them — is told so by
+    // the first read of its probe (its bit of the home slot's field is clear; false positives ~ load / 16) instead of
+    // walking to the next empty slot, and the divergent probe loop below only runs for words that are (almost surely) there.
     for(int i = tid; i < n1; i += 64 * kScoreWaves)
     {
-        uint32_t h = (qw[i] * 2654435761u) >> 7 & hmask;
-        while(atomicCAS(&table[h], 0u, (uint32_t)i + 1u) != 0u)
-            h = (h + 1) & hmask;
+        const uint32_t hw = qw[i] * 2654435761u;
+        const uint32_t home = hw >> 7 & hmask;
+        uint32_t h = home;
+        for(;;)
+        {
+            const uint32_t e = table[h];
+            if((e & kIdxMask) != 0u)
+            {
+                h = (h + 1) & hmask;
+                continue;
+            }
+            if(atomicCAS(&table[h], e, e | ((uint32_t)i + 1u)) == e)
+                break; // (a failed exchange: another thread took the slot or set one of its Bloom bits — look again)
+        }
+        atomicOr(&table[home], 1u << (kIdxBits + (hw >> 28)));
     }
     __syncthreads();
 
@@ -535,21 +552,25 @@ __global__ __launch_bounds__(64 * kScoreWaves) void k_bow_score(
             bool found = false;
             if(i < n2)
             {
-                uint32_t h = (word * 2654435761u) >> 7 & hmask;
-                for(;;)
-                {
-                    const uint32_t e = table[h];
-                    if(e == 0)
-                        break;
-                    if(qw[e - 1] == word)
+                const uint32_t hw = word * 2654435761u;
+                uint32_t h = hw >> 7 & hmask;
+                uint32_t e = table[h];
+                if((e >> (kIdxBits + (hw >> 28))) & 1u) // else: no query word with this home slot and Bloom bit
+                    for(;;)
                     {
-                        const double vi = qv[e - 1];
-                        c = fabs(vi - wi) - fabs(vi) - fabs(wi);
-                        found = true;
-                        break;
+                        const uint32_t idx = e & kIdxMask;
+                        if(idx == 0)
+                            break;
+                        if(qw[idx - 1] == word)
+                        {
+                            const double vi = qv[idx - 1];
+                            c = fabs(vi - wi) - fabs(vi) - fabs(wi);
+                            found = true;
+                            break;
+                        }
+                        h = (h + 1) & hmask;
+                        e = table[h];
                     }
-                    h = (h + 1) & hmask;
-                }
             }
             const unsigned long long m = __ballot(found);
             if(found)

@@ -44,10 +44,8 @@ def compare(dump, frames, out=print):
 
     def check(name, ok, note=""):
         nonlocal bad
-        # descriptors may differ where the dumping host's libm cosf / sinf differs from include/mslam_sincos.h: reported, not counted
-        soft = name.endswith("orb descriptors")
-        bad += 0 if (ok or soft) else 1
-        out("%-4s %s %s" % ("PASS" if ok else ("NOTE" if soft else "FAIL"), name, note))
+        bad += 0 if ok else 1
+        out("%-4s %s %s" % ("PASS" if ok else "FAIL", name, note))
     for f in range(2):
         F = "f%d_" % f
         bgr = np.ascontiguousarray(frames[f])
@@ -85,7 +83,15 @@ def compare(dump, frames, out=print):
         dd = sum(np.array_equal(d["desc"][mine[k]], rdesc[theirs[k]]) for k in common)
         check(F + "orb angles", ang == len(common), "%d / %d" % (ang, len(common)))
         check(F + "orb harris responses", resp == len(common), "%d / %d" % (resp, len(common)))
-        check(F + "orb descriptors", dd == len(common), "%d / %d equal (differences may stem from libm cosf/sinf)" % (dd, len(common)))
+        # descriptors may differ where the dumping host's libm cosf / sinf differs from the correctly rounded value in the last
+        # bit (a rotated sample coordinate within ~1e-6 of .5 then rounds the other way): a BOUNDED tolerance — at least
+        # 99 % of the common keypoints identical, the others differing in at most 8 of their 256 bits — and the tolerated
+        # count is part of the record
+        diff_bits = [int(np.unpackbits(d["desc"][mine[k]] ^ rdesc[theirs[k]]).sum()) for k in common]
+        n_diff = sum(b != 0 for b in diff_bits)
+        ok_desc = len(common) > 0 and n_diff <= 0.01 * len(common) and max(diff_bits, default=0) <= 8
+        check(F + "orb descriptors", ok_desc, "%d / %d equal, %d differ (tolerated: <= 1 %%, <= 8 bits each; worst %d bits; libm cosf/sinf)" % (
+            dd, len(common), n_diff, max(diff_bits, default=0)))
     a = np.array([[orc.fast_atan2(float(y * 977), float(x * 1013)) for x in range(-40, 41)] for y in range(-40, 41)], np.float32)
     check("fast_atan2", np.array_equal(a, dump["fast_atan2"]))
     i0, i1, d0, d1 = orc.match_knn2_raw(dump["f1_orb_descriptors"], dump["f0_orb_descriptors"])
