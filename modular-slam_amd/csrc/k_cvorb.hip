@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
     // 18-dword rows, so the five LDS reads of a wave are linear in the lane index.
     {
         const uint32_t* T = reinterpret_cast<const uint32_t*>(tile);
-        const uint32_t thr2 = (uint32_t)thr * 0x00010001u;
+        const int tq = min(max(thr, 0), 254);
+        const uint32_t kb = (uint32_t)(256 - ((tq + 256) >> 1)) * 0x01010101u; // bit 7 of lerp(q, kb): q >= (t + 256) >> 1
+        const uint32_t kd = (uint32_t)(255 - ((254 - tq) >> 1)) * 0x01010101u; // bit 7 of lerp(q, kd): q >  (254 - t) >> 1
         // tested tile columns [c_lo, c_hi) and scored rows [r_lo, r_hi): FAST's 3-pixel frame of the level
         const int c_lo = max(3, 7 - X0), c_hi = min(69, w - 3 - (X0 - 4));
         const int r_lo = max(0, 4 - Y0), r_hi = min(66, h - 3 - (Y0 - 1));
@@ -194,21 +196,17 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
                 const uint32_t U = row[-3 * (kSP / 4)], D = row[3 * (kSP / 4)];
                 const uint32_t Lf = __builtin_amdgcn_alignbyte(C, L, 1); // columns x-3 of the four pixels
                 const uint32_t Rt = __builtin_amdgcn_alignbyte(R, C, 3); // columns x+3
-                uint32_t k[2];
-#pragma unroll
-                for(int hh = 0; hh < 2; ++hh)
-                {
-                    const uint32_t sel = hh == 0 ? 0x0c010c00u : 0x0c030c02u; // bytes (0,1) or (2,3) as u16 lanes
-                    typedef short s16x2 __attribute__((ext_vector_type(2)));
-                    auto wd = [&](uint32_t v) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, v, sel)); };
-                    const s16x2 t2 = __builtin_bit_cast(s16x2, thr2);
-                    const s16x2 cc = wd(C), hi = cc + t2, lo = cc - t2;
-                    const s16x2 p0 = wd(D), p4 = wd(Rt), p8 = wd(U), p12 = wd(Lf);
-                    const s16x2 mb = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12));
-                    const s16x2 md = __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
-                    k[hh] = __builtin_bit_cast(uint32_t, (s16x2)(hi - mb)) | __builtin_bit_cast(uint32_t, (s16x2)(md - lo));
-                }
-                keep = __builtin_amdgcn_perm(k[1], k[0], 0x07050301u) & colmask;
+                // the byte-wise compass test of k_fast_cells (k_fast.hip, phase A): q = (p - c + 255) >> 1 of four pixels per
+                // v_lerp_u8, thresholds as bit 7 of a second lerp; a superset of the exact test (the survivors get the exact
+                // arc score below)
+                const uint32_t nC = ~C;
+                const uint32_t q0 = __builtin_amdgcn_lerp(D, nC, 0u), q8 = __builtin_amdgcn_lerp(U, nC, 0u);
+                const uint32_t q4 = __builtin_amdgcn_lerp(Rt, nC, 0u), q12 = __builtin_amdgcn_lerp(Lf, nC, 0u);
+                const uint32_t br = (__builtin_amdgcn_lerp(q0, kb, 0u) | __builtin_amdgcn_lerp(q8, kb, 0u)) &
+                                    (__builtin_amdgcn_lerp(q4, kb, 0u) | __builtin_amdgcn_lerp(q12, kb, 0u));
+                const uint32_t nd = (__builtin_amdgcn_lerp(q0, kd, 0u) & __builtin_amdgcn_lerp(q8, kd, 0u)) |
+                                    (__builtin_amdgcn_lerp(q4, kd, 0u) & __builtin_amdgcn_lerp(q12, kd, 0u));
+                keep = (br | ~nd) & colmask;
             }
             // compaction: wave-wide inclusive scan of the per-lane counts with DPP adds, one LDS atomic per wave
             const uint32_t cnt = (uint32_t)__popc(keep);
