@@ -77,6 +77,7 @@ __device__ __forceinline__ float util_sin(float v)
 
 constexpr int kPatchR = 18;               // the rotated pattern reaches |18| (its radius is 18.38; the reference keeps a 19-px border)
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
+constexpr int kPatchRowsT = kPatchRows + 1;  // tiled plane: the fetched window starts at an even row (whole tile rows): 38
 constexpr int kPatchDw = 12;              // 48-byte rows: 37 needed bytes from a 16-byte aligned start, or from 12 bytes past one
 #ifndef MSLAM_DISC_DW
 #define MSLAM_DISC_DW 16
@@ -85,6 +86,16 @@ constexpr int kPatchDwT = 16;             // tiled blurred plane (below): up to 
 constexpr int kPatchBufsT = 4;            // ... and a 4-slot ring (37 x 64 bytes per slot: 37.9 KB per workgroup, 4 workgroups per CU)
 constexpr int kPatchBufs = 5;            // LDS patch ring per wave: one being sampled, four in flight (3 / 4 / 5 slots of 1776 bytes: 0.505 / 0.493 / 0.486 ms per 500 frames; 35.5 KB per workgroup = 4 workgroups per CU: with 5 (4 slots) the frames in flight per XCD outgrow its L2 and the memory-side reads rise from 1.9 to 2.2 MB per frame)
 constexpr int kBlocksPerFrame = 32;
+
+// dst[lane sel] = val (both wave-uniform): v_writelane_b32.  Inline asm (this compiler has no builtin for it): the lane select
+// goes through M0 (a VOP3 instruction takes one SGPR besides it), and the s_nop covers the wait states gfx950 wants between
+// a vector instruction that wrote `val`'s scalar register (a ballot, a v_readlane) and a vector instruction that reads it —
+// the compiler inserts them for its own instructions, not in front of inline asm.
+__device__ __forceinline__ uint32_t write_lane(uint32_t dst, uint32_t val, int sel)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(val), "s"(sel) : "m0");
+    return dst;
+}
 
 // 64-lane integer sum with DPP adds (VALU only, no LDS crossbar); the total lands in lane 63
 __device__ __forceinline__ int wave_sum_dpp(int v)
@@ -146,7 +157,7 @@ template <bool TILED>
 __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bpf)
 {
     constexpr int kBufs = TILED ? kPatchBufsT : kPatchBufs;
-    constexpr int kSlotDw = kPatchRows * (TILED ? kPatchDwT : kPatchDw);
+    constexpr int kSlotDw = TILED ? kPatchRowsT * kPatchDwT : kPatchRows * kPatchDw;
     constexpr int kDiscDw = TILED ? MSLAM_DISC_DW : 12; // LDS row pitch of the raw disc window in dwords
     __shared__ __attribute__((aligned(16))) uint32_t patch[4][kBufs][kSlotDw];
 
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
         //         batch; the per-keypoint phases then only broadcast lane k's registers (v_readlane).
         uint32_t my_kp = 0;
         int my_level = 0;
-        uint32_t my_doff = 0, my_poff = 0, my_pitch = 16, my_sh = 0, my_pxy = 0;
+        uint32_t my_doff = 0, my_poff = 0, my_pitch = 16, my_sh = 0, my_lut = 0;
         float my_scale = 1.f, my_resp = 0.f;
         {
             const int idx = base + lane * kStr; // position in the frame's concatenated keypoint list (:787-808)
@@ -258,11 +269,22 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 my_resp = a.sel_resp ? a.sel_resp[si] : (float)kp_score(my_kp);
                 const int px = kp_x(my_kp) + kBorder, py = kp_y(my_kp) + kBorder; // :966-967
                 my_doff = lofs + (uint32_t)(py - 15) * my_pitch + (uint32_t)((px - 15) & ~15);
-                if(TILED) // level offset; the patch's first 16-byte column and first row ride in my_pxy
-                    my_poff = lofs, my_pxy = (uint32_t)((px - kPatchR) & ~15) | ((uint32_t)(py - kPatchR) << 16);
+                my_sh = (uint32_t)((px - 15) & 15) | ((uint32_t)((px - kPatchR) & 15) << 4);
+                if(TILED)
+                {
+                    // Tiled plane (common.hpp: tiled_off): byte (x, y) = (y & ~1) pitch + (y & 1) 64 + 2 (x & ~63) + (x & 63).  The
+                    // window is fetched from the EVEN row ya & ~1 on (38 rows) in 16-byte chunks starting at xa = 64 A + 16 a:
+                    // everything that depends on the keypoint only is folded into ONE scalar offset (my_poff) and the four
+                    // column terms of chunk c = 0 .. 3, ((a + c) + ((a + c) & 4)) in units of 16 bytes, into the bytes of my_lut
+                    // — what is left per lane is a multiply-add on lane constants (dma_patch)
+                    const uint32_t xa = (uint32_t)((px - kPatchR) & ~15), ya = (uint32_t)(py - kPatchR);
+                    my_poff = lofs + (ya & ~1u) * my_pitch + 2u * (xa & ~63u);
+                    const uint32_t sum = 0x03020100u + ((xa >> 4) & 3u) * 0x01010101u;       // a + c per byte
+                    my_lut = sum + (((sum + 0x7C7C7C7Cu) & 0x80808080u) >> 5);              // + 4 where a + c >= 4
+                    my_sh |= (ya & 1u) << 8;                                                 // the patch's first row inside the window
+                }
                 else
                     my_poff = lofs + (uint32_t)(py - kPatchR) * my_pitch + (uint32_t)((px - kPatchR) & ~15);
-                my_sh = (uint32_t)((px - 15) & 15) | ((uint32_t)((px - kPatchR) & 15) << 4);
             }
         }
         // The candidate words are in registers from here on: without this explicit wait the compiler re-inserts
@@ -285,10 +307,14 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                     const uint32_t t = (uint32_t)lane + 64u * q;
                     if(kDiscDw == 16)
                     {
-                        // four lanes per row (the fourth idle): every quad of lanes asks for ONE row, i.e. one cache line
+                        // four lanes per row (the fourth idle): every quad of lanes asks for ONE row, i.e. one cache line.  Row
+                        // (lane >> 2) + 16 q: the lane's part of the address is one multiply-add on lane constants, the
+                        // instruction's part (16 q rows) is scalar
+                        const uint8_t* sq = src + (size_t)(16u * q * pitch);
+                        asm volatile("" : "+s"(sq));
                         if(t < 124u && (t & 3u) != 3u)
                             __builtin_amdgcn_global_load_lds(
-                                (const __attribute__((address_space(1))) void*)(src + __umul24(t >> 2, pitch) + 16u * (t & 3u)),
+                                (const __attribute__((address_space(1))) void*)(sq + (__umul24((uint32_t)lane >> 2, pitch) + 16u * ((uint32_t)lane & 3u))),
                                 (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
                     }
                     else if(t < 93u)
@@ -320,8 +346,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 }
                 int t10, t01;
                 wave_sum_dpp2(m10, m01, t10, t01);
-                my_m10 = lane == k ? t10 : my_m10;
-                my_m01 = lane == k ? t01 : my_m01;
+                my_m10 = (int)write_lane((uint32_t)my_m10, (uint32_t)t10, k);
+                my_m01 = (int)write_lane((uint32_t)my_m01, (uint32_t)t01, k);
             };
             constexpr int kDepthA = kBufs - 1;
 #pragma unroll
@@ -363,38 +389,37 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
             const uint32_t shp = (bc(my_sh, k) >> 4) & 15u;
             if(TILED)
             {
-                // chunk (row, c) of the patch = bytes [xa + 16 c, + 16) of image row ya + row (common.hpp: tiled_off)
-                const uint32_t pxy = bc(my_pxy, k);
-                const uint32_t xa = pxy & 0xFFFFu, ya = pxy >> 16;
-                const uint32_t pitchT = pitch * (uint32_t)kTileH;
-                auto chunk_off = [&](uint32_t row, uint32_t c) {
-                    const uint32_t x = xa + 16u * c, yy = ya + row;
-                    return __umul24(yy >> kTileHLog, pitchT) + ((x >> kTileWLog) << 7) + ((yy & (uint32_t)(kTileH - 1)) << kTileWLog) +
-                           (x & (uint32_t)(kTileW - 1));
-                };
+                // (see phase 0) lane part of a chunk's address: (row & ~1) pitch + (row & 1) 64 + 16 lut[c]; the rows of the
+                // instructions after the first differ by an even number (16 resp. 20), i.e. by a scalar
+                const uint32_t lut = bc(my_lut, k);
                 if(shp > 11u)
                 {
+                    // four chunks per row: chunk t = lane + 64 q is (row (lane >> 2) + 16 q, c = lane & 3); 38 rows = 152 chunks
+                    const uint32_t lo = (__builtin_amdgcn_ubfe(lut, 8u * ((uint32_t)lane & 3u), 8u) << 4) +
+                                        (__umul24(((uint32_t)lane >> 3) << 1, pitch) + (((uint32_t)lane & 4u) << 4));
 #pragma unroll
                     for(int q = 0; q < 3; ++q)
                     {
-                        const uint32_t t = (uint32_t)lane + 64u * q;
-                        if(t < (uint32_t)(kPatchRows * 4))
-                            __builtin_amdgcn_global_load_lds(
-                                (const __attribute__((address_space(1))) void*)(bsrc + chunk_off(t >> 2, t & 3u)),
-                                (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                        const uint8_t* bq = bsrc + (size_t)(16u * q * pitch);
+                        asm volatile("" : "+s"(bq)); // (a scalar base per instruction: else the compiler adds the rows to the lane offsets in 64-bit vector adds)
+                        if((uint32_t)lane + 64u * q < (uint32_t)(kPatchRowsT * 4))
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bq + lo),
+                                                             (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
                     }
                 }
                 else
                 {
+                    // three chunks per row, 60 lanes per instruction: chunk t = lane + 60 q is (row lane / 3 + 20 q, c = lane % 3)
+                    const uint32_t r3 = ((uint32_t)lane * 21846u) >> 16, c3 = (uint32_t)lane - 3u * r3;
+                    const uint32_t lo = (__builtin_amdgcn_ubfe(lut, 8u * c3, 8u) << 4) + (__umul24(r3 & ~1u, pitch) + ((r3 & 1u) << 6));
 #pragma unroll
                     for(int q = 0; q < 2; ++q)
                     {
-                        const uint32_t t = (uint32_t)lane + 64u * q;
-                        const uint32_t row = (t * 21846u) >> 16; // t / 3
-                        if(t < (uint32_t)(kPatchRows * 3))
-                            __builtin_amdgcn_global_load_lds(
-                                (const __attribute__((address_space(1))) void*)(bsrc + chunk_off(row, t - 3u * row)),
-                                (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 256], 16, 0, 0);
+                        const uint8_t* bq = bsrc + (size_t)(20u * q * pitch);
+                        asm volatile("" : "+s"(bq));
+                        if((uint32_t)lane < (q == 0 ? 60u : (uint32_t)(kPatchRowsT * 3 - 60)))
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bq + lo),
+                                                             (__attribute__((address_space(3))) void*)&patch[wave][buf][q * 240], 16, 0, 0);
                     }
                 }
                 return;
@@ -457,15 +482,21 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 f32x2 ca2 = f32x2{ca, ca}, sa2 = f32x2{sa, sa};
                 asm volatile("" : "+v"(ca2), "+v"(sa2)); // keep them vector register pairs (not re-associated onto the scalars)
                 const f32x2 magic = f32x2{12582912.f, 12582912.f};
-                const uint8_t* lp = reinterpret_cast<const uint8_t*>(patch[wave][buf]);
-                const uint32_t shp = (bc(my_sh, k) >> 4) & 15u;
+                const uint32_t lp_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)patch[wave][buf];
+                const uint32_t shk = bc(my_sh, k);
+                const uint32_t shp = (shk >> 4) & 15u, odd_row = (shk >> 8) & 1u;
                 unsigned long long bits[4];
                 // row-major plane: 48-byte row pitch; the row starts at the aligned chunk (shp <= 11) or 12 bytes past it (see
                 // dma_patch).  Tiled plane: the row always starts at the aligned chunk; 48-byte pitch when shp <= 11, else 64.
                 auto sample = [&](auto wide) {
                     constexpr bool WIDE = decltype(wide)::value;
                     constexpr uint32_t P = WIDE ? 64u : 48u;
-                    const uint32_t ctr_off = (uint32_t)(kPatchR * P + kPatchR) + (TILED || shp <= 11u ? shp : shp - 12u) - (P + 1u) * 0x4B400000u;
+                    // LDS byte address of a sample = patch base + row * P + column.  The magic-number sums carry rint(v) in their
+                    // low bits on top of 0x4B400000: row * P as a 24-bit multiply-add (which only sees 0x400000 + row) or a shift-add
+                    // with the column's bit pattern as the addend — one full-rate instruction per sample (the compiler made a
+                    // 32-bit v_mul_lo, a quarter-rate instruction, out of (r << 5) + (r << 4)) — and everything constant in `ctr`
+                    const uint32_t ctr = lp_lds + (uint32_t)(kPatchR * P + kPatchR) + (TILED ? shp + odd_row * P : shp <= 11u ? shp : shp - 12u) -
+                                         (WIDE ? P * 0x4B400000u : P * 0x00400000u) - 0x4B400000u;
 #pragma unroll
                     for(int t = 0; t < 4; ++t)
                     {
@@ -473,11 +504,10 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                         const f32x2 rr = (patX[t] * sa2 + patY[t] * ca2) + magic;
                         const f32x2 cc = (patX[t] * ca2 - patY[t] * sa2) + magic;
                         const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y);
-                        // row * P + byte in row
-                        const uint32_t i0 = WIDE ? (r0 << 6) + __float_as_uint(cc.x) + ctr_off : (r0 << 5) + (r0 << 4) + __float_as_uint(cc.x) + ctr_off;
-                        const uint32_t i1 = WIDE ? (r1 << 6) + __float_as_uint(cc.y) + ctr_off : (r1 << 5) + (r1 << 4) + __float_as_uint(cc.y) + ctr_off;
-                        const int v0 = lp[i0];
-                        const int v1 = lp[i1];
+                        const uint32_t i0 = (WIDE ? (r0 << 6) + __float_as_uint(cc.x) : __umul24(r0, P) + __float_as_uint(cc.x)) + ctr;
+                        const uint32_t i1 = (WIDE ? (r1 << 6) + __float_as_uint(cc.y) : __umul24(r1, P) + __float_as_uint(cc.y)) + ctr;
+                        const int v0 = *(const __attribute__((address_space(3))) uint8_t*)i0;
+                        const int v1 = *(const __attribute__((address_space(3))) uint8_t*)i1;
                         bits[t] = __ballot(v0 < v1);
                     }
                 };
@@ -494,11 +524,10 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                 // the batch's descriptors are collected in lanes (4 k + t holds dword pair t of keypoint k) and stored once per batch — one store instruction instead of sixteen on the
                 // memory pipeline the window fetches are queued on
 #pragma unroll
-                for(int t = 0; t < 4; ++t)
+                for(int t = 0; t < 4; ++t) // (v_writelane: one instruction per dword, the ballots are scalars already)
                 {
-                    const bool mine = lane == 4 * k + t;
-                    desc_lo = mine ? (uint32_t)bits[t] : desc_lo;
-                    desc_hi = mine ? (uint32_t)(bits[t] >> 32) : desc_hi;
+                    desc_lo = write_lane(desc_lo, (uint32_t)bits[t], 4 * k + t);
+                    desc_hi = write_lane(desc_hi, (uint32_t)(bits[t] >> 32), 4 * k + t);
                 }
             };
             static_assert(kBufs >= 2 && kBufs <= 5, "the vmcnt immediates of phases A and C cover up to four younger windows");
