@@ -662,26 +662,16 @@ def main():
                 copy_stream = torch.cuda.Stream()
                 ev_in = [torch.cuda.Event() for _ in range(2)]
                 ev_free = [torch.cuda.Event() for _ in range(2)]
-                K = ctx.params.max_keypoints
-                host_out = {}
+                # results: ONE packed block per batch (mslam_hip_pack_batch_dev: exactly count[t] keypoint / match_count[t] match
+                # records per frame), written by the pack kernel straight into page-locked host memory — nothing but the
+                # records that exist crosses PCIe; two blocks alternate
+                pcap = ctx.packed_capacity(PB, True)
+                host_pk = [torch.empty(pcap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+                pk_turn = [0]
 
                 def results_to_host():
-                    v, pv = ctx.batch_view(), ctx.points_view()
-                    ctx.join_matcher()
-                    with torch.cuda.stream(ts):
-                        for name, ptr, shape, dt in (("count", v.count, (PB,), torch.int32), ("xy", v.xy, (PB, K, 2), torch.float32),
-                                                     ("desc", v.desc, (PB, K, 32), torch.uint8),
-                                                     ("angle", v.angle, (PB, K), torch.float32),
-                                                     ("octave", v.octave, (PB, K), torch.int32),
-                                                     ("mfrom", v.match_from, (PB, K), torch.int32),
-                                                     ("mto", v.match_to, (PB, K), torch.int32),
-                                                     ("mcount", v.match_count, (PB,), torch.int32),
-                                                     ("xyz", pv.xyz, (PB, K, 3), torch.float64),
-                                                     ("valid", pv.valid, (PB, K), torch.uint8)):
-                            src = view_as_tensor(ptr, shape, dt)
-                            if name not in host_out:
-                                host_out[name] = torch.empty(shape, dtype=dt).pin_memory()
-                            host_out[name].copy_(src, non_blocking=True)
+                    ctx.pack_batch_dev(host_pk[pk_turn[0] & 1].data_ptr(), pcap, True)
+                    pk_turn[0] += 1
 
                 def h2d(i):
                     with torch.cuda.stream(copy_stream):
@@ -708,14 +698,16 @@ def main():
                 t0 = time.perf_counter()
                 run_pcie(n_pb)
                 dt_p = time.perf_counter() - t0
-                kp_p = int(host_out["count"].sum()) * n_pb
-                d2h = sum(t.numel() * t.element_size() for t in host_out.values())
+                pk = pkg.unpack_batch(host_pk[(pk_turn[0] - 1) & 1].numpy())
+                kp_p = int(pk["kp_offset"][-1]) * n_pb
+                d2h = pk["bytes"]
                 extras["pcie_inclusive"] = {
                     "frames_per_s": n_pb * PB / dt_p, "keypoints_per_s": kp_p / dt_p,
                     "h2d_GBps": n_pb * (h_rgb.numel() + 2 * h_dep.numel()) / dt_p / 1e9, "d2h_GBps": n_pb * d2h / dt_p / 1e9,
                     "how": "%d batches of %d frames: RGB + depth from pinned host memory by double-buffered async H2D on a "
                            "copy stream, overlapped with extract + match + back-projection of the previous batch; keypoints, "
-                           "descriptors, matches and 3-D points (capacity-strided arrays) copied back to pinned host memory; "
+                           "descriptors, matches and 3-D points packed on the device (exactly `count` records per frame, "
+                           "mslam_hip_pack_batch_dev) and written by the pack kernel into page-locked host memory; "
                            "the headline `value` is the HBM-resident rate" % (n_pb, PB)}
 
             if world == 1 and rank == 0 and not a.no_legs and not cv and not a.bow and not a.pnp:

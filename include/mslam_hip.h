@@ -270,6 +270,29 @@ typedef struct
 } mslam_hip_points_view;
 int mslam_hip_get_points_view(mslam_hip_ctx* ctx, mslam_hip_points_view* view);
 
+/* ---- packed results of a batch (one transfer instead of capacity-strided arrays) --------------------------------------
+ * The batch views above are [max_batch][max_keypoints]-strided; copied back as they are, more than half of the bytes are
+ * padding.  mslam_hip_pack_batch_dev writes, on the context's stream (after the matcher has been joined), a header, the
+ * per-frame offset tables and then exactly count[t] keypoint records / match_count[t] match records per frame, back to
+ * back, into `out`: device memory (follow with ONE copy of header.bytes) or page-locked, device-mapped host memory (the
+ * kernel's stores are the transfer; read the header after synchronising).  Frame t's keypoints are records
+ * kp_offset[t] .. kp_offset[t+1]-1 of every keypoint array, its matches records match_offset[t] .. match_offset[t+1]-1
+ * (match indices are relative to the frame, as in the views).  If the results do not fit capacity_bytes, header.fits is 0,
+ * header.bytes tells what was needed, nothing else is written and mslam_hip_sync reports MSLAM_HIP_E_CAPACITY.
+ * mslam_hip_packed_capacity: an upper bound for n_frames frames (every frame at max_keypoints). */
+typedef struct
+{
+    int32_t n_frames, total_keypoints, total_matches, with_points;
+    uint64_t off_kp_offset, off_match_offset;            /* int32[n_frames + 1] each                         */
+    uint64_t off_xy, off_desc, off_octave, off_angle, off_response; /* f32[.][2], u8[.][32], i32, f32, f32   */
+    uint64_t off_xyz, off_valid;                         /* f64[.][3], u8[.] (with_points)                   */
+    uint64_t off_match_from, off_match_to;               /* i32[total_matches] each                          */
+    uint64_t bytes;                                      /* bytes used (or needed, when fits == 0)           */
+    int32_t fits, pad;
+} mslam_hip_packed_header;
+int mslam_hip_pack_batch_dev(mslam_hip_ctx* ctx, void* out, size_t capacity_bytes, int with_points);
+size_t mslam_hip_packed_capacity(const mslam_hip_ctx* ctx, int n_frames, int with_points);
+
 /* ---- IPnpAlgorithm::solvePnp (the consumer of the matches) ------------------------------------
  * Replaces OpenCvRansacPnp::solvePnp's cv::solvePnPRansac call (cv_ransac_pnp.cpp:56-57: useExtrinsicGuess = true, 100
  * iterations, 5 px, confidence 0.99, no distortion).  object_points = n x 3 f32 (landmark states cast to float, :22-31),

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "mslam_hip_last_match_kernel",
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
     "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size", "mslam_hip_qlz_decompress",
-    "mslam_hip_pnp_ransac", "mslam_hip_pnp_batch_dev", "mslam_hip_get_pnp_view", "mslam_hip_pnp_set_confidence",
+    "mslam_hip_pnp_ransac", "mslam_hip_pnp_batch_dev", "mslam_hip_get_pnp_view", "mslam_hip_pnp_set_confidence", "mslam_hip_pack_batch_dev", "mslam_hip_packed_capacity",
 ]
 
 
@@ -69,6 +69,35 @@ class BatchView(C.Structure):
 
 class PointsView(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("xyz", C.c_void_p), ("valid", C.c_void_p)]
+
+
+class PackedHeader(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("total_keypoints", C.c_int32), ("total_matches", C.c_int32), ("with_points", C.c_int32),
+                ("off_kp_offset", C.c_uint64), ("off_match_offset", C.c_uint64), ("off_xy", C.c_uint64), ("off_desc", C.c_uint64),
+                ("off_octave", C.c_uint64), ("off_angle", C.c_uint64), ("off_response", C.c_uint64), ("off_xyz", C.c_uint64),
+                ("off_valid", C.c_uint64), ("off_match_from", C.c_uint64), ("off_match_to", C.c_uint64), ("bytes", C.c_uint64),
+                ("fits", C.c_int32), ("pad", C.c_int32)]
+
+
+def unpack_batch(buf):
+    """numpy views of a buffer written by mslam_hip_pack_batch_dev (buf: 1-D uint8 array holding at least header.bytes)"""
+    h = PackedHeader.from_buffer_copy(bytes(buf[:C.sizeof(PackedHeader)]))
+    if not h.fits:
+        raise MslamHipError(E_CAPACITY, "packed results need %d bytes" % h.bytes)
+    nk, nm, nf = h.total_keypoints, h.total_matches, h.n_frames
+
+    def arr(off, dt, n, *shape):
+        return np.frombuffer(buf, dt, n, int(off)).reshape((-1,) + shape) if shape else np.frombuffer(buf, dt, n, int(off))
+    out = {"n_frames": nf, "bytes": int(h.bytes),
+           "kp_offset": arr(h.off_kp_offset, np.int32, nf + 1), "match_offset": arr(h.off_match_offset, np.int32, nf + 1),
+           "xy": arr(h.off_xy, np.float32, 2 * nk, 2), "desc": arr(h.off_desc, np.uint8, 32 * nk, 32),
+           "octave": arr(h.off_octave, np.int32, nk), "angle": arr(h.off_angle, np.float32, nk),
+           "response": arr(h.off_response, np.float32, nk),
+           "match_from": arr(h.off_match_from, np.int32, nm), "match_to": arr(h.off_match_to, np.int32, nm)}
+    if h.with_points:
+        out["xyz"] = arr(h.off_xyz, np.float64, 3 * nk, 3)
+        out["valid"] = arr(h.off_valid, np.uint8, nk)
+    return out
 
 
 class PnpView(C.Structure):
@@ -110,6 +139,9 @@ def lib():
         L.mslam_hip_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
         L.mslam_hip_destroy.argtypes = [C.c_void_p]
         L.mslam_hip_destroy.restype = None
+        L.mslam_hip_packed_capacity.restype = C.c_size_t
+        L.mslam_hip_packed_capacity.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mslam_hip_pack_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _lib = L
     return _lib
 
@@ -236,6 +268,14 @@ class Context:
         self._chk(self.L.mslam_hip_backproject_batch_dev(self._h, C.c_void_p(d_depth_ptr), C.c_float(factor),
                                                          C.c_double(focal[0]), C.c_double(focal[1]),
                                                          C.c_double(principal[0]), C.c_double(principal[1])))
+
+    def pack_batch_dev(self, out_ptr, capacity_bytes, with_points=True):
+        """exactly count[t] keypoint / match_count[t] match records per frame of the last batch, back to back, into out_ptr
+        (device memory or page-locked mapped host memory) on the context's stream; parse with unpack_batch()"""
+        self._chk(self.L.mslam_hip_pack_batch_dev(self._h, C.c_void_p(out_ptr), C.c_size_t(capacity_bytes), 1 if with_points else 0))
+
+    def packed_capacity(self, n_frames, with_points=True):
+        return int(self.L.mslam_hip_packed_capacity(self._h, int(n_frames), 1 if with_points else 0))
 
     def points_view(self):
         v = PointsView()

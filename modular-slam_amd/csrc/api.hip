@@ -782,6 +782,8 @@ static int check_flags(mslam_hip_ctx* c)
         m += " the BoW database is full (mslam_hip_bow_db_reserve);";
     if(f & kFlagBowPackOverflow)
         m += " a BoW vector has more words than the exchange format's k_max;";
+    if(f & kFlagPackOverflow)
+        m += " packed batch results larger than the buffer given to mslam_hip_pack_batch_dev (header.bytes);";
     return fail(c, MSLAM_HIP_E_CAPACITY, m);
 }
 

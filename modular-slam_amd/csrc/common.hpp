@@ -78,7 +78,8 @@ enum : uint32_t
     kFlagKpOverflow = 2u,    // more keypoints in a frame than max_keypoints
     kFlagQuadNoConverge = 4u, // quadtree pass limit hit (cannot happen for sane sizes)
     kFlagBowPackOverflow = 8u, // a BoW vector has more words than the exchange format's k_max
-    kFlagDbFull = 16u          // the BoW database's posting log is full (mslam_hip_bow_db_reserve)
+    kFlagDbFull = 16u,         // the BoW database's posting log is full (mslam_hip_bow_db_reserve)
+    kFlagPackOverflow = 32u    // mslam_hip_pack_batch_dev: the packed results do not fit the caller's buffer
 };
 
 // ---- kernel launchers (each enqueues on `s`, no synchronisation) ----------------------------------

@@ -60,6 +60,143 @@ using namespace mslam;
         }                                                                                                              \
     } while(0)
 
+
+// ---- packed results of a batch (mslam_hip_pack_batch_dev) ---------------------------------------------------------------
+// The batch views are capacity-strided ([max_batch][max_keypoints]...): copied back as they are, more than half of what
+// crosses PCIe is padding.  k_pack_plan turns the per-frame counts into offsets (one workgroup, a 1024-wide scan) and writes
+// the header; k_pack_copy then moves exactly count[t] keypoint records and match_count[t] match records per frame behind it.
+// `out` may be device memory (one copy of header.bytes follows) or page-locked, device-mapped host memory (the kernel's
+// stores ARE the transfer).
+__global__ __launch_bounds__(1024) void k_pack_plan(const int32_t* __restrict__ count, const int32_t* __restrict__ mcount, int n_frames,
+                                                    int cap, int with_points, unsigned long long capacity_bytes, uint8_t* __restrict__ out,
+                                                    uint32_t* __restrict__ flags)
+{
+    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    mslam_hip_packed_header* h = reinterpret_cast<mslam_hip_packed_header*>(out);
+    const unsigned long long hdr = (sizeof(mslam_hip_packed_header) + 15) & ~15ull;
+    const unsigned long long tab = (((unsigned long long)(n_frames + 1) * 4) + 15) & ~15ull;
+    const bool room_for_tables = capacity_bytes >= hdr + 2 * tab;
+    int32_t* kp_off = reinterpret_cast<int32_t*>(out + hdr);
+    int32_t* m_off = reinterpret_cast<int32_t*>(out + hdr + tab);
+    if(tid < 2)
+        carry[tid] = 0;
+    __syncthreads();
+    for(int base = 0; base < n_frames; base += 1024)
+    {
+        const int t = base + tid;
+        uint32_t v[2] = {t < n_frames ? (uint32_t)min(max(count[t], 0), cap) : 0u, t < n_frames ? (uint32_t)min(max(mcount[t], 0), cap) : 0u};
+        uint32_t inc[2];
+#pragma unroll
+        for(int k = 0; k < 2; ++k)
+        {
+            uint32_t x = v[k];
+            for(int o = 1; o < 64; o <<= 1)
+            {
+                const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+                x += lane >= o ? y : 0u;
+            }
+            inc[k] = x;
+            if(lane == 63)
+                wsum[k][wave] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for(int k = 0; k < 2; ++k)
+        {
+            uint32_t pre = carry[k];
+            for(int w = 0; w < wave; ++w)
+                pre += wsum[k][w];
+            if(t < n_frames && room_for_tables)
+                (k == 0 ? kp_off : m_off)[t] = (int32_t)(pre + inc[k] - v[k]);
+        }
+        __syncthreads();
+        if(tid < 2)
+        {
+            uint32_t tot = carry[tid];
+            for(int w = 0; w < 16; ++w)
+                tot += wsum[tid][w];
+            carry[tid] = tot;
+        }
+        __syncthreads();
+    }
+    if(tid == 0)
+    {
+        const unsigned long long nk = carry[0], nm = carry[1];
+        auto al = [](unsigned long long x) { return (x + 15) & ~15ull; };
+        unsigned long long o = hdr + 2 * tab;
+        mslam_hip_packed_header hh;
+        hh.n_frames = n_frames, hh.total_keypoints = (int32_t)nk, hh.total_matches = (int32_t)nm, hh.with_points = with_points;
+        hh.off_kp_offset = hdr, hh.off_match_offset = hdr + tab;
+        hh.off_xy = o, o = al(o + nk * 8);
+        hh.off_desc = o, o = al(o + nk * 32);
+        hh.off_octave = o, o = al(o + nk * 4);
+        hh.off_angle = o, o = al(o + nk * 4);
+        hh.off_response = o, o = al(o + nk * 4);
+        hh.off_xyz = o, o = al(o + (with_points ? nk * 24 : 0));
+        hh.off_valid = o, o = al(o + (with_points ? nk : 0));
+        hh.off_match_from = o, o = al(o + nm * 4);
+        hh.off_match_to = o, o = al(o + nm * 4);
+        hh.bytes = o;
+        hh.fits = o <= capacity_bytes ? 1 : 0;
+        hh.pad = 0;
+        if(capacity_bytes >= sizeof(hh))
+            *h = hh;
+        if(room_for_tables)
+            kp_off[n_frames] = (int32_t)nk, m_off[n_frames] = (int32_t)nm;
+        if(!hh.fits)
+            atomicOr(flags, kFlagPackOverflow);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_copy(const float* __restrict__ xy, const uint8_t* __restrict__ desc, const int32_t* __restrict__ octave,
+                                                   const float* __restrict__ angle, const float* __restrict__ response,
+                                                   const double* __restrict__ xyz, const uint8_t* __restrict__ valid,
+                                                   const int32_t* __restrict__ mfrom, const int32_t* __restrict__ mto, int cap,
+                                                   uint8_t* __restrict__ out)
+{
+    const mslam_hip_packed_header* h = reinterpret_cast<const mslam_hip_packed_header*>(out);
+    if(!h->fits)
+        return;
+    const int t = blockIdx.x, tid = blockIdx.y * 256 + threadIdx.x, nt = gridDim.y * 256;
+    const int32_t* kp_off = reinterpret_cast<const int32_t*>(out + h->off_kp_offset);
+    const int32_t* m_off = reinterpret_cast<const int32_t*>(out + h->off_match_offset);
+    const size_t k0 = (size_t)kp_off[t], m0 = (size_t)m_off[t];
+    const int n = kp_off[t + 1] - kp_off[t], m = m_off[t + 1] - m_off[t];
+    const size_t f = (size_t)t * cap;
+    uint2* o_xy = reinterpret_cast<uint2*>(out + h->off_xy) + k0;
+    uint2* o_desc = reinterpret_cast<uint2*>(out + h->off_desc) + 4 * k0; // (8-byte pieces: a frame's first record is 32-byte aligned only)
+    uint32_t* o_oct = reinterpret_cast<uint32_t*>(out + h->off_octave) + k0;
+    uint32_t* o_ang = reinterpret_cast<uint32_t*>(out + h->off_angle) + k0;
+    uint32_t* o_resp = reinterpret_cast<uint32_t*>(out + h->off_response) + k0;
+    for(int i = tid; i < 4 * n; i += nt)
+        o_desc[i] = reinterpret_cast<const uint2*>(desc)[4 * f + i];
+    for(int i = tid; i < n; i += nt)
+    {
+        o_xy[i] = reinterpret_cast<const uint2*>(xy)[f + i];
+        o_oct[i] = reinterpret_cast<const uint32_t*>(octave)[f + i];
+        o_ang[i] = reinterpret_cast<const uint32_t*>(angle)[f + i];
+        o_resp[i] = reinterpret_cast<const uint32_t*>(response)[f + i];
+    }
+    if(h->with_points)
+    {
+        double* o_xyz = reinterpret_cast<double*>(out + h->off_xyz) + 3 * k0;
+        uint8_t* o_val = out + h->off_valid + k0;
+        for(int i = tid; i < 3 * n; i += nt)
+            o_xyz[i] = xyz[3 * f + i];
+        for(int i = tid; i < n; i += nt)
+            o_val[i] = valid[f + i];
+    }
+    uint32_t* o_mf = reinterpret_cast<uint32_t*>(out + h->off_match_from) + m0;
+    uint32_t* o_mt = reinterpret_cast<uint32_t*>(out + h->off_match_to) + m0;
+    for(int i = tid; i < m; i += nt)
+    {
+        o_mf[i] = reinterpret_cast<const uint32_t*>(mfrom)[f + i];
+        o_mt[i] = reinterpret_cast<const uint32_t*>(mto)[f + i];
+    }
+}
+
 static int pfail(mslam_hip_ctx* c, const char* m)
 {
     c->err = m;
@@ -100,6 +237,38 @@ int mslam_hip_backproject_batch_dev(mslam_hip_ctx* c, const uint16_t* d_depth, f
                        c->p.max_keypoints, c->d_xyz, c->d_valid);
     PHIPCHK(c, hipGetLastError());
     return MSLAM_HIP_OK;
+}
+
+int mslam_hip_pack_batch_dev(mslam_hip_ctx* c, void* out, size_t capacity_bytes, int with_points)
+{
+    if(!c)
+        return MSLAM_HIP_E_INVALID;
+    if(!out || capacity_bytes < sizeof(mslam_hip_packed_header))
+        return pfail(c, "pack_batch_dev: no output buffer (at least the header must fit)");
+    if(c->n_last < 1)
+        return pfail(c, "pack_batch_dev: no detect batch");
+    if(with_points && !c->d_xyz)
+        return pfail(c, "pack_batch_dev: with_points without a back-projected batch");
+    PHIPCHK(c, hipSetDevice(c->p.device));
+    int rc = mslam_hip_join_matcher(c); // the matches come from the matcher's own stream
+    if(rc)
+        return rc;
+    const size_t K = (size_t)c->p.max_keypoints;
+    hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(1024), 0, c->stream, c->d_count + 1, c->d_mcount, c->n_last, c->p.max_keypoints,
+                       with_points ? 1 : 0, (unsigned long long)capacity_bytes, static_cast<uint8_t*>(out), c->d_flags);
+    hipLaunchKernelGGL(k_pack_copy, dim3(c->n_last, 4), dim3(256), 0, c->stream, c->d_xy + K * 2, c->d_desc + K * 32, c->d_octave + K,
+                       c->d_angle + K, c->d_response + K, c->d_xyz, c->d_valid, c->d_mfrom, c->d_mto, c->p.max_keypoints,
+                       static_cast<uint8_t*>(out));
+    PHIPCHK(c, hipGetLastError());
+    return MSLAM_HIP_OK;
+}
+
+size_t mslam_hip_packed_capacity(const mslam_hip_ctx* c, int n_frames, int with_points)
+{
+    if(!c || n_frames < 0)
+        return 0;
+    const size_t K = (size_t)c->p.max_keypoints, n = (size_t)n_frames;
+    return 256 + 2 * (((n + 1) * 4 + 15) & ~(size_t)15) + n * K * (8 + 32 + 4 + 4 + 4 + (with_points ? 25 : 0) + 8) + 16 * 16;
 }
 
 int mslam_hip_get_points_view(mslam_hip_ctx* c, mslam_hip_points_view* v)

@@ -318,6 +318,53 @@ def test_backproject_batch_device(pkg, orc, synth_frames):
     c.close()
 
 
+def test_packed_batch_results(pkg, synth_frames):
+    """mslam_hip_pack_batch_dev: exactly count[t] keypoint records and match_count[t] match records per frame, back to back,
+    equal to the capacity-strided views frame by frame; a buffer that is too small is reported, not overrun"""
+    import torch
+    B, K = 5, 4096
+    frames = synth_frames[:B]
+    dev = torch.from_numpy(frames).cuda()
+    depth = torch.from_numpy(np.full((B, 480, 640), 7000, np.uint16).view(np.int16)).cuda()
+    c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K)
+    c.detect_batch_dev(dev.data_ptr(), B)
+    c.match_batch_dev(0.7, False)
+    c.backproject_batch_dev(depth.data_ptr())
+    cap = c.packed_capacity(B)
+    buf = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    c.pack_batch_dev(buf.data_ptr(), cap, True)
+    c.sync()
+    p = pkg.unpack_batch(buf.cpu().numpy())
+    v, pv = c.batch_view(), c.points_view()
+    cnt = pkg.read_device(c, v.count, (B,), np.int32)
+    mc = pkg.read_device(c, v.match_count, (B,), np.int32)
+    assert p["n_frames"] == B and p["bytes"] < cap // 2
+    assert np.array_equal(np.diff(p["kp_offset"]), cnt) and np.array_equal(np.diff(p["match_offset"]), mc)
+    full = {"xy": pkg.read_device(c, v.xy, (B, K, 2), np.float32), "desc": pkg.read_device(c, v.desc, (B, K, 32), np.uint8),
+            "octave": pkg.read_device(c, v.octave, (B, K), np.int32), "angle": pkg.read_device(c, v.angle, (B, K), np.float32),
+            "response": pkg.read_device(c, v.response, (B, K), np.float32), "xyz": pkg.read_device(c, pv.xyz, (B, K, 3), np.float64),
+            "valid": pkg.read_device(c, pv.valid, (B, K), np.uint8)}
+    mf = pkg.read_device(c, v.match_from, (B, K), np.int32)
+    mt = pkg.read_device(c, v.match_to, (B, K), np.int32)
+    for t in range(B):
+        a, b = p["kp_offset"][t], p["kp_offset"][t + 1]
+        for k, arr in full.items():
+            assert np.array_equal(p[k][a:b].view(np.uint8), arr[t, :cnt[t]].view(np.uint8)), (t, k)
+        a, b = p["match_offset"][t], p["match_offset"][t + 1]
+        assert np.array_equal(p["match_from"][a:b], mf[t, :mc[t]]) and np.array_equal(p["match_to"][a:b], mt[t, :mc[t]])
+    assert cnt.min() > 1000 and mc[1:].min() > 100
+    # too small: nothing but the header is written, header.fits == 0, and the context reports it
+    small = torch.full((4096,), 0xAB, dtype=torch.uint8, device="cuda")
+    c.pack_batch_dev(small.data_ptr(), 4096, True)
+    with pytest.raises(pkg.MslamHipError):
+        c.sync()
+    h = small.cpu().numpy()
+    with pytest.raises(pkg.MslamHipError):
+        pkg.unpack_batch(h)
+    assert (h[1024:] == 0xAB).all()
+    c.close()
+
+
 def test_full_size_batch_properties(pkg, orc, synth_frames):
     """cfg2-sized launch (250 frames in one batch): size-independent properties instead of a 250-frame oracle run —
     identical frames give identical outputs wherever they sit in the batch, a frame matched against an identical
