@@ -662,7 +662,7 @@ static int create_impl(mslam_hip_ctx* c)
             const int want = e ? atoi(e) : kMaxLevels;
             const char* k = getenv("MSLAM_HIP_LEVEL_K6");
             const char* ks = getenv("MSLAM_HIP_LEVEL_K6_SMALL");
-            c->level_k6_small = ks ? std::max(1, atoi(ks)) : 1;
+            c->level_k6_small = ks ? std::max(0, atoi(ks)) : 0; // a handful of frames: 2-row blocks (a wave walks 8 rows instead of 14)
             c->level_k6 = k ? std::max(1, atoi(k)) : 9; // 9 -> 56-row blocks: the halo re-reads cost 11 % instead of 19 % (32 rows); the step time is the same
             const bool fits = (p.width & 3) == 0 && (double)B * p.width * p.height * 3 < 4294967296.0 &&
                               (double)B * g.slab < 4294901760.0 /* below k_level.hip's kDropLane */ && (size_t)B * (p.width / 4) < (1u << 22) && p.height >= 8;
@@ -855,7 +855,11 @@ static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, co
     ra.frame0 = f0, ra.n_frames = nf;
     ra.quads = (dl.w + 3) / 4;
     ra.inv_quads = 1.0f / (float)ra.quads;
-    ra.k6 = std::max(1, std::min(std::min(k6, 9), (dl.h - 2) / 6));
+    // (k6 = 0, the single-frame launches: 2-row blocks pay on the smaller levels only — measured per level, 640x480 pyramid:
+    // 333 rows and below 6.0-8.0 -> 4.7-7.6 us, 400 rows and above 7.9-8.2 -> 9.6-10.3 us)
+    if(k6 == 0 && dl.h >= 380)
+        k6 = 1;
+    ra.k6 = std::max(k6 == 0 ? 0 : 1, std::min(std::min(k6, 9), (dl.h - 2) / 6));
     // small levels: a launch of long row blocks is a single wave per SIMD or less and runs as long as ONE wave's walk.
     // Shorten the blocks (more halo rows, more waves) until the launch has about two waves per SIMD.
     {
@@ -907,7 +911,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 ga.n_frames = nf, ga.frame0 = f0;
                 ga.quads = g.W / 4;
                 ga.inv_quads = 1.0f / (float)ga.quads;
-                ga.k6 = std::max(1, std::min(k6_batch, (g.H - 2) / 6));
+                ga.k6 = std::max(k6_batch == 0 && g.H < 380 ? 0 : 1, std::min(k6_batch, (g.H - 2) / 6));
                 ga.blur_tiled = g.blur_tiled;
                 ga.bk = make_blur_k();
                 launch_gray_blur(ga, cs);

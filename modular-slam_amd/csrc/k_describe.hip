@@ -154,7 +154,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // this kernel pays for is lines).  A tiled row can only be fetched in aligned 16-byte chunks: three when the patch starts at
 // byte <= 11 of its first chunk, else four (LDS row pitch 48 / 64 bytes, wave-uniform per keypoint).
 template <bool TILED>
-__global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bpf)
+__global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bpf, int kb)
 {
     constexpr int kBufs = TILED ? kPatchBufsT : kPatchBufs;
     constexpr int kSlotDw = TILED ? kPatchRowsT * kPatchDwT : kPatchRows * kPatchDw;
@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
     // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by linear id, so all kBlocksPerFrame
     // workgroups of a frame are given ids with the same (id & 7): the two level slabs of a frame (1.9 MB)
     // are then gathered through ONE 4 MB L2 instead of being pulled into all eight.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int f_local = (slot / bpf) * 8 + xcd;
+    // (kb < kBatch: a handful of frames — the synchronous single-frame calls: fewer keypoints per wave, more workgroups, and
+    // the workgroups of the one frame on all XCDs: that launch runs at the latency of one wave's batch)
+    const bool spread = kb < kBatch;
+    const int xcd = blockIdx.x & 7, slot = spread ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+    const int f_local = spread ? slot / bpf : (slot / bpf) * 8 + xcd;
     if(f_local >= a.n_frames)
         return;
     const int bx = slot % bpf;
@@ -228,9 +231,9 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
     // measured 0.529 vs 0.487 ms per 500 frames.  (Ranking the 64 by (level, column band, row) first bought another
     // 0.01 ms and cost 0.02 ms in the serial head of every batch; 8- and 16-wave workgroups: 0.51 / 0.66 ms.)
     constexpr int kStr = 4;
-    for(int base = bx * 4 * kBatch + wave; base < n_kp; base += bpf * 4 * kBatch)
+    for(int base = bx * 4 * kb + wave; base < n_kp; base += bpf * 4 * kb)
     {
-        const int n_here = min(kBatch, (n_kp - base + kStr - 1) / kStr); // wave-uniform
+        const int n_here = min(kb, (n_kp - base + kStr - 1) / kStr); // wave-uniform
 
         // ---- 0. one lane per keypoint: which level, which candidate word, and everything phases A and C need to
         //         address its two windows (byte offsets inside the frame slab, row pitch, sub-16 shifts).  The level
@@ -579,12 +582,16 @@ void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_fra
     aa.n_frames = n_frames;
     static const int bpf_env = [] { const char* e = getenv("MSLAM_DESC_BPF"); return e ? atoi(e) : 0; }();
     // a handful of frames (the synchronous single-frame call): twice the workgroups per frame, half the keypoints per wave
-    const int bpf = bpf_env ? bpf_env : n_frames < 8 ? 2 * kBlocksPerFrame : kBlocksPerFrame;
-    const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)bpf;
+    // a handful of frames (the synchronous single-frame call): 4 keypoints per wave and batch instead of 16, 128 workgroups per frame
+    static const int kb_env = [] { const char* e = getenv("MSLAM_DESC_KB_SMALL"); return e ? atoi(e) : 0; }();
+    const bool small = n_frames < 8;
+    const int kb = small ? (kb_env >= 1 && kb_env <= kBatch ? kb_env : 4) : kBatch;
+    const int bpf = bpf_env ? bpf_env : small ? 4 * kBlocksPerFrame : kBlocksPerFrame;
+    const unsigned grid = kb < kBatch ? (unsigned)n_frames * (unsigned)bpf : (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)bpf;
     if(g.blur_tiled)
-        hipLaunchKernelGGL(k_describe<true>, dim3(grid), dim3(256), 0, s, gg, aa, bpf);
+        hipLaunchKernelGGL(k_describe<true>, dim3(grid), dim3(256), 0, s, gg, aa, bpf, kb);
     else
-        hipLaunchKernelGGL(k_describe<false>, dim3(grid), dim3(256), 0, s, gg, aa, bpf);
+        hipLaunchKernelGGL(k_describe<false>, dim3(grid), dim3(256), 0, s, gg, aa, bpf, kb);
 }
 
 } // namespace mslam

@@ -69,8 +69,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // (profiles/r02_a_pmc_fetch_write_per_launch.json); all cells of a frame now get ids with the same (id & 7).
     // (grid: x = cell * 8 + XCD, y = group of 8 frames — the XCD of a workgroup follows its linear id, and gridDim.x is a
     // multiple of 8; no division, and the cell's descriptor comes through the scalar unit)
-    const int xcd = blockIdx.x & 7, cell_id = (int)(blockIdx.x >> 3);
-    const int f_local = (int)blockIdx.y * 8 + xcd;
+    // A handful of frames (the synchronous single-frame calls, n_frames < 8): grid x = cell, y = frame — the cells of the one
+    // frame spread over all XCDs; that launch is latency-bound, not memory-bound.
+    const bool spread = n_frames < 8;
+    const int xcd = blockIdx.x & 7, cell_id = spread ? (int)blockIdx.x : (int)(blockIdx.x >> 3);
+    const int f_local = spread ? (int)blockIdx.y : (int)blockIdx.y * 8 + xcd;
     if(f_local >= n_frames)
         return;
     const size_t frame = (size_t)f_local + g.frame0;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
                  uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s)
 {
-    const dim3 grid(8u * (unsigned)g.n_cells, (unsigned)((n_frames + 7) / 8));
+    const dim3 grid = n_frames < 8 ? dim3((unsigned)g.n_cells, (unsigned)n_frames) : dim3(8u * (unsigned)g.n_cells, (unsigned)((n_frames + 7) / 8));
     Geometry gg = g;
     gg.frame0 = frame0;
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, d_pyr, gg, d_cells, d_cell_cnt, d_cell_kp, ini_thr, min_thr,

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
     MSLAM_ROW(2, false, false, 2, false);
     MSLAM_ROW(3, false, true, 3, true);
     MSLAM_ROW(4, false, true, 4, true);
-    MSLAM_ROW(5, false, true, 5, true);
+    MSLAM_ROW(5, false, true, 5, R > 2); // (a 2-row block — k6 = 0, the single-frame launches — ends at row 4: row 5 is a halo row)
 #pragma unroll 1
     for(int i0 = 6; i0 < R + 4; i0 += 6)
     {
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     MSLAM_ROW(2, false, false, 2, false);
     MSLAM_ROW(3, false, true, 3, true);
     MSLAM_ROW(4, false, true, 4, true);
-    MSLAM_ROW(5, false, true, 5, true);
+    MSLAM_ROW(5, false, true, 5, R > 2); // (a 2-row block — k6 = 0, the single-frame launches — ends at row 4: row 5 is a halo row)
 #pragma unroll 1
     for(int i0 = 6; i0 < R + 4; i0 += 6)
     {
