@@ -771,6 +771,8 @@ def main():
 
                 def guard(name, fn):
                     """a leg that fails is recorded under <name>_error and the remaining legs still run"""
+                    if name in os.environ.get("MSLAM_BENCH_SKIP_LEGS", "").split(","):
+                        return
                     try:
                         fn()
                     except Exception as e:  # noqa: BLE001
@@ -788,6 +790,35 @@ def main():
                                          "cfg3: the cfg2 step + DBoW3 transform (k=10, L=%d: %d words), tf-idf + L1 vectors, scores vs the "
                                          "last 64 frames, inverted-file adds" % (a.voc_levels, 10 ** a.voc_levels))
                 guard('cfg3', _leg_cfg3)
+
+                def _leg_cfg5():
+                    # cfg5: 1920x1080, 3 levels, ~10 k keypoints per frame, k = 2 matcher with ratio test (64 M+ distances per frame)
+                    W5, H5, B5 = 1920, 1080, 64
+                    f5 = synth.make_stream(B5, W5, H5, seed=4321)
+                    d5 = torch.from_numpy(f5).cuda()
+                    dd5 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W5, H5, seed=4321)[0]] * B5)).view(np.int16)).cuda()
+                    area5 = -(-W5 * H5 // (640 * 480))
+                    ks5 = area5 * max(1, 1000 // 370)
+                    ts5 = torch.cuda.Stream()
+                    ctx5 = pkg.Context(width=W5, height=H5, max_batch=B5, n_levels=3, min_node_area=370,
+                                       max_keypoints=min(32736, 4096 * ks5), max_candidates=16384 * area5, device=dev,
+                                       stream=ts5.cuda_stream)
+
+                    def step5(i):
+                        ctx5.detect_batch_dev(d5.data_ptr(), B5)
+                        ctx5.match_batch_dev(0.7, True)
+                        ctx5.backproject_batch_dev(dd5.data_ptr())
+                    step5(0)
+                    ctx5.sync()
+                    kp5 = int(pkg.read_device(ctx5, ctx5.batch_view().count, (B5,), np.int32).sum())
+                    cand5 = int(ctx5.debug_counts(pkg.DBG_CANDIDATES, B5).sum())
+                    extras["cfg5"] = leg("cfg5", ctx5, step5, B5, 10, kp5, cand5, a.voc_levels,
+                                         "cfg5: synthetic 1920x1080 RGB-D stream (%d distinct frames), 3-level pyramid, min-area 370, "
+                                         "extract + knn-2 ratio-test matcher vs previous frame + back-projection" % B5)
+                    ctx5.close()
+                    del d5, dd5, f5
+
+                guard('cfg5', _leg_cfg5)
 
                 def _leg_cfg2_k2000():
                     # cfg2 at BASELINE.json's nominal K: the quadtree's stop area tuned so that a frame keeps 2000 +- 2 % keypoints
@@ -864,34 +895,6 @@ def main():
                     del d4, dd4, f4
                 guard('cfg4_one_rank', _leg_cfg4_one_rank)
 
-                def _leg_cfg5():
-                    # cfg5: 1920x1080, 3 levels, ~10 k keypoints per frame, k = 2 matcher with ratio test (64 M+ distances per frame)
-                    W5, H5, B5 = 1920, 1080, 64
-                    f5 = synth.make_stream(B5, W5, H5, seed=4321)
-                    d5 = torch.from_numpy(f5).cuda()
-                    dd5 = torch.from_numpy(np.ascontiguousarray(np.stack([synth.make_depth(1, W5, H5, seed=4321)[0]] * B5)).view(np.int16)).cuda()
-                    area5 = -(-W5 * H5 // (640 * 480))
-                    ks5 = area5 * max(1, 1000 // 370)
-                    ts5 = torch.cuda.Stream()
-                    ctx5 = pkg.Context(width=W5, height=H5, max_batch=B5, n_levels=3, min_node_area=370,
-                                       max_keypoints=min(32736, 4096 * ks5), max_candidates=16384 * area5, device=dev,
-                                       stream=ts5.cuda_stream)
-
-                    def step5(i):
-                        ctx5.detect_batch_dev(d5.data_ptr(), B5)
-                        ctx5.match_batch_dev(0.7, True)
-                        ctx5.backproject_batch_dev(dd5.data_ptr())
-                    step5(0)
-                    ctx5.sync()
-                    kp5 = int(pkg.read_device(ctx5, ctx5.batch_view().count, (B5,), np.int32).sum())
-                    cand5 = int(ctx5.debug_counts(pkg.DBG_CANDIDATES, B5).sum())
-                    extras["cfg5"] = leg("cfg5", ctx5, step5, B5, 10, kp5, cand5, a.voc_levels,
-                                         "cfg5: synthetic 1920x1080 RGB-D stream (%d distinct frames), 3-level pyramid, min-area 370, "
-                                         "extract + knn-2 ratio-test matcher vs previous frame + back-projection" % B5)
-                    ctx5.close()
-                    del d5, dd5, f5
-
-                guard('cfg5', _leg_cfg5)
 
                 def _leg_latency_us():
                     # ---- what the reference's caller sees: ONE frame per call through the synchronous C-ABI entry points

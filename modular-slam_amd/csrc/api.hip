@@ -545,7 +545,9 @@ static int create_impl(mslam_hip_ctx* c)
         }
         const char* fb = getenv("MSLAM_HIP_FORK_BLUR");
         c->fork_blur = fb && atoi(fb) != 0;
-        for(int k = 0; k < 4; ++k)
+        // (only when asked for: every stream of a process is dealt to one of a few hardware queues, and streams that share a
+        // queue run one after the other — idle streams here can push a later context's chunk / matcher streams onto one queue)
+        for(int k = 0; k < 4 && c->fork_blur; ++k)
         {
             HIPCHK(c, hipStreamCreateWithFlags(&c->blur_stream[k], hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_blur_fork[k], hipEventDisableTiming));
@@ -727,6 +729,9 @@ static int create_impl(mslam_hip_ctx* c)
         HIPCHK(c, hipEventCreateWithFlags(&o.ev_detect, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&o.ev_match, hipEventDisableTiming));
     }
+    // (the chunk streams and this one should sit on different hardware queues: streams that share a queue run one after the
+    // other.  Giving them different PRIORITY classes to force that was measured — cfg5 380 -> 308 M, a second 640x480 context
+    // 625 -> 491 M keypoints/s: the low class starves — and is not done.)
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream_m, hipStreamNonBlocking));
     {
         const char* e = getenv("MSLAM_HIP_OVERLAP_MATCH");

@@ -55,6 +55,16 @@ __host__ __device__ __forceinline__ unsigned tiled_off(unsigned pitch, int x, in
     return (unsigned)(y >> kTileHLog) * (pitch * (unsigned)kTileH) + (unsigned)(x >> kTileWLog) * 128u +
            (unsigned)(y & (kTileH - 1)) * (unsigned)kTileW + (unsigned)(x & (kTileW - 1));
 }
+// an LDS pointer from a 32-bit LDS byte offset (device pass: LDS pointers are 32 bits wide; the host pass only parses this)
+template <class P>
+__device__ __forceinline__ P lds_ptr(uint32_t off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (P)off;
+#else
+    return (P)(uintptr_t)off;
+#endif
+}
 // FAST cell: a sub-image [x0, x0+cw) x [y0, y0+ch) of one level (:880-905).
 struct CellDesc
 {

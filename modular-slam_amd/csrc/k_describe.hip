@@ -88,12 +88,17 @@ constexpr int kPatchBufs = 5;            // LDS patch ring per wave: one being s
 constexpr int kBlocksPerFrame = 32;
 
 // dst[lane sel] = val (both wave-uniform): v_writelane_b32.  Inline asm (this compiler has no builtin for it): the lane select
-// goes through M0 (a VOP3 instruction takes one SGPR besides it), and the s_nop covers the wait states gfx950 wants between
-// a vector instruction that wrote `val`'s scalar register (a ballot, a v_readlane) and a vector instruction that reads it —
-// the compiler inserts them for its own instructions, not in front of inline asm.
+// goes through M0 (a VOP3 instruction takes one SGPR besides it) — saved and restored around the instruction, because M0 is
+// a register the compiler manages on its own (the LDS-DMA base) and does not track through asm clobbers — and the s_nop
+// covers the wait states gfx950 wants between a vector instruction that wrote `val`'s scalar register (a ballot, a
+// v_readlane) and a vector instruction that reads it: the compiler inserts them for its own instructions, not in front of
+// inline asm.
 __device__ __forceinline__ uint32_t write_lane(uint32_t dst, uint32_t val, int sel)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tv_writelane_b32 %0, %1, m0" : "+v"(dst) : "s"(val), "s"(sel) : "m0");
+    uint32_t keep_m0;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(dst), "=&s"(keep_m0)
+                 : "s"(val), "s"(sel));
     return dst;
 }
 
@@ -509,8 +514,8 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
                         const uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y);
                         const uint32_t i0 = (WIDE ? (r0 << 6) + __float_as_uint(cc.x) : __umul24(r0, P) + __float_as_uint(cc.x)) + ctr;
                         const uint32_t i1 = (WIDE ? (r1 << 6) + __float_as_uint(cc.y) : __umul24(r1, P) + __float_as_uint(cc.y)) + ctr;
-                        const int v0 = *(const __attribute__((address_space(3))) uint8_t*)i0;
-                        const int v1 = *(const __attribute__((address_space(3))) uint8_t*)i1;
+                        const int v0 = *lds_ptr<const __attribute__((address_space(3))) uint8_t*>(i0);
+                        const int v1 = *lds_ptr<const __attribute__((address_space(3))) uint8_t*>(i1);
                         bits[t] = __ballot(v0 < v1);
                     }
                 };

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     if(!CHECKED || (colmask != 0 && y < ch - 3))
                     {
                         // the four tested pixels are dword i + 1 of the row
-                        const lds32_t r = (lds32_t)row;
+                        const lds32_t r = lds_ptr<lds32_t>(row);
                         const uint32_t d0 = r[60], d1 = r[61], d2 = r[62];
                         const uint32_t nC = ~d1, U = r[1], D = r[121];
                         const uint32_t Lf = __builtin_amdgcn_alignbyte(d1, d0, 1); // columns x-3 of the four pixels
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     const bool any = keep != 0;
                     const unsigned long long vote = __ballot(any);
                     if(any)
-                        ((lds32_t)seg_lds)[n_grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u))] =
+                        lds_ptr<lds32_t>(seg_lds)[n_grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u))] =
                             keep | yx;
                     n_grp += (uint32_t)__popcll(vote);
                 }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             // expansion of the wave's records: pixel k of a record goes to the list slot given by the ballot of flag k
             for(uint32_t i0 = 0; i0 < n_grp; i0 += 64)
             {
-                const uint32_t rec = i0 + ln < n_grp ? ((lds32_t)seg_lds)[i0 + ln] : 0u;
+                const uint32_t rec = i0 + ln < n_grp ? lds_ptr<lds32_t>(seg_lds)[i0 + ln] : 0u;
                 const bool f0 = (rec & 0x80u) != 0, f1 = (rec & 0x8000u) != 0, f2 = (rec & 0x800000u) != 0, f3 = (int)rec < 0;
                 const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
                 const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2),
@@ -236,22 +236,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 // (byte addresses, the wave-uniform part of each in a scalar: one v_lshl_add per store address)
                 uint32_t b2 = cand_lds + 2u * base;
                 if(f0)
-                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)v;
+                    *lds_ptr<lds16_t>(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)v;
                 b2 += 2u * c0;
                 if(f1)
-                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)(v + 1);
+                    *lds_ptr<lds16_t>(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)(v + 1);
                 b2 += 2u * c1;
                 if(f2)
-                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u))) = (uint16_t)(v + 2);
+                    *lds_ptr<lds16_t>(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u))) = (uint16_t)(v + 2);
                 b2 += 2u * c2;
                 if(f3)
-                    *(lds16_t)(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, 0u))) = (uint16_t)(v + 3);
+                    *lds_ptr<lds16_t>(b2 + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, 0u))) = (uint16_t)(v + 3);
             }
             // the segment's storage becomes score map again (bytes beyond the four segments were cleared at the start)
             {
                 uint32_t z = 0;
                 asm volatile("" : "+v"(z)); // (a zero made here: hoisted, a uint4 of zeros holds four registers through the kernel)
-                ((lds128_t)seg_lds)[ln] = u32x4_t{z, z, z, z};
+                lds_ptr<lds128_t>(seg_lds)[ln] = u32x4_t{z, z, z, z};
             }
         }
         __syncthreads();
