@@ -1148,6 +1148,7 @@ int mslam_hip_detect_batch_dev(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_fra
         return rc;
     HIPCHK(c, hipEventRecord(c->out[c->cur].ev_detect, c->stream));
     c->n_last = n_frames;
+    ++c->detect_seq;
     return MSLAM_HIP_OK;
 }
 
@@ -1236,6 +1237,7 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     }
     HIPCHK(c, hipEventRecord(c->out[c->cur].ev_detect, c->stream));
     c->n_last = 1;
+    ++c->detect_seq;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint32_t flags;
     int32_t n;

@@ -107,6 +107,8 @@ struct mslam_hip_ctx
     float* d_response = nullptr;
     int32_t* d_count = nullptr;
     int n_last = 0;         // frames in the last detect batch
+    unsigned long long detect_seq = 0; // counts detect batches; points_seq = the batch the back-projected points belong to
+    unsigned long long points_seq = ~0ull;
     bool have_prev = false; // slot 0 holds a real predecessor of the current batch
 
     // matcher

@@ -236,6 +236,7 @@ int mslam_hip_backproject_batch_dev(mslam_hip_ctx* c, const uint16_t* d_depth, f
                        c->p.width, c->p.height, cam, c->d_xy + K * 2, (long long)K * 2, c->d_count + 1, 0,
                        c->p.max_keypoints, c->d_xyz, c->d_valid);
     PHIPCHK(c, hipGetLastError());
+    c->points_seq = c->detect_seq;
     return MSLAM_HIP_OK;
 }
 
@@ -247,8 +248,8 @@ int mslam_hip_pack_batch_dev(mslam_hip_ctx* c, void* out, size_t capacity_bytes,
         return pfail(c, "pack_batch_dev: no output buffer (at least the header must fit)");
     if(c->n_last < 1)
         return pfail(c, "pack_batch_dev: no detect batch");
-    if(with_points && !c->d_xyz)
-        return pfail(c, "pack_batch_dev: with_points without a back-projected batch");
+    if(with_points && (!c->d_xyz || c->points_seq != c->detect_seq))
+        return pfail(c, "pack_batch_dev: with_points, but the last detect batch has not been back-projected");
     PHIPCHK(c, hipSetDevice(c->p.device));
     int rc = mslam_hip_join_matcher(c); // the matches come from the matcher's own stream
     if(rc)
