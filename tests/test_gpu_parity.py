@@ -329,9 +329,11 @@ def test_packed_batch_results(pkg, synth_frames):
     c = pkg.Context(width=640, height=480, max_batch=B, max_keypoints=K)
     c.detect_batch_dev(dev.data_ptr(), B)
     c.match_batch_dev(0.7, False)
-    c.backproject_batch_dev(depth.data_ptr())
     cap = c.packed_capacity(B)
     buf = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    with pytest.raises(pkg.MslamHipError):          # 3-D points asked for, but this batch has not been back-projected
+        c.pack_batch_dev(buf.data_ptr(), cap, True)
+    c.backproject_batch_dev(depth.data_ptr())
     c.pack_batch_dev(buf.data_ptr(), cap, True)
     c.sync()
     p = pkg.unpack_batch(buf.cpu().numpy())
