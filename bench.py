@@ -163,6 +163,10 @@ def parse():
                     help="skip the legs after the timed region (popcount matcher, serialized stages, PCIe-inclusive, "
                          "exchange): what the profiling passes use")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="single-GPU runs: create a one-rank process group on the nccl (= RCCL) backend and issue the cfg4 leg's "
+                         "all-gather as a real RCCL collective instead of the world-1 device copy (what one GPU can exercise of "
+                         "the RCCL path; not part of the default run: a box without a usable RCCL would hang it)")
     return ap.parse_args()
 
 
@@ -858,7 +862,14 @@ def main():
                                        max_candidates=16384 * area4, device=dev, stream=ts4.cuda_stream)
                     ctx4.bow_load(voc)
                     ctx4.bow_db_reserve(32 * B4)
-                    cross4 = CrossStreamLoopCandidates(k_max=2048)
+                    if a.rccl_world1 and not dist.is_initialized():
+                        s1 = socket.socket()
+                        s1.bind(("127.0.0.1", 0))
+                        port1 = s1.getsockname()[1]
+                        s1.close()
+                        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port1, rank=0, world_size=1,
+                                                device_id=torch.device("cuda", dev))
+                    cross4 = CrossStreamLoopCandidates(k_max=2048, always_collective=a.rccl_world1)
 
                     def step4(i):
                         ctx4.detect_batch_dev(d4.data_ptr(), B4)
@@ -888,7 +899,9 @@ def main():
                     l4["exchange"] = {"bytes_per_collective": 4 * set_dwords(B4, cross4.k_max), "k_max": cross4.k_max,
                                       "collectives_per_step": 1.0 if n_coll else 0.0,
                                       "ms_per_batch_alone": (time.perf_counter() - t0) / 10 * 1e3,
-                                      "what": "mslam_hip_bow_pack_dev -> all_gather_into_tensor (world 1: a device copy of the set) -> "
+                                      "collective": ("all_gather_into_tensor on the %s backend, world size 1" % dist.get_backend())
+                                      if (a.rccl_world1 and dist.is_initialized()) else "world 1: a device copy of the set",
+                                      "what": "mslam_hip_bow_pack_dev -> all_gather_into_tensor -> "
                                               "mslam_hip_bow_cross_score_packed_dev on the communication stream"}
                     extras["cfg4_one_rank"] = l4
                     ctx4.close()
@@ -949,6 +962,8 @@ def main():
     ctx.close()
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif a.rccl_world1 and dist.is_initialized():
         dist.destroy_process_group()
     if watchdog is not None:
         watchdog.cancel()

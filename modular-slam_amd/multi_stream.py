@@ -62,9 +62,12 @@ def unpack_set(buf, n_frames, k_max):
 
 
 class CrossStreamLoopCandidates:
-    def __init__(self, k_max=2048, group=None):
+    def __init__(self, k_max=2048, group=None, always_collective=False):
         self.k_max = k_max
         self.group = group
+        # world 1 normally short-cuts the gather to a device copy; always_collective issues the collective anyway (what a
+        # single-GPU box can exercise of the RCCL path: tests/test_gpu_bow.py::test_rccl_world1_exchange)
+        self.always_collective = always_collective
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._comm = None      # communication stream (GPU path)
@@ -84,7 +87,7 @@ class CrossStreamLoopCandidates:
             h_out = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(h_out.view(-1), local_set.cpu(), group=self.group)
             out.copy_(h_out)
-        elif self.world > 1:
+        elif self.world > 1 or (self.always_collective and dist.is_initialized()):
             dist.all_gather_into_tensor(out.view(-1), local_set, group=self.group)
         else:
             out[0].copy_(local_set)
