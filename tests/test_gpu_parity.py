@@ -84,6 +84,27 @@ def test_detect_flat_and_noise_frames(pkg, orc, ctx):
     c.close()
 
 
+def test_fast_dense_cells(pkg, orc):
+    """k_fast_cells with nearly every pixel a candidate (noise at thresholds 3 / 1): the record segments of phase A fill up
+    (64 groups per step), the expansion runs several rounds, and the short list of passing pixels overflows its 512 entries —
+    the NMS phase then walks the full candidate list; stage by stage and end to end against the oracle.  Second frame:
+    saturated black / white blocks (c + t and c - t leave the byte range: the biased-difference test has no saturation case)."""
+    rng = np.random.default_rng(17)
+    noise = rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)
+    blocks = np.repeat(np.repeat(rng.integers(0, 2, (30, 40), dtype=np.uint8) * 255, 8, 0), 8, 1)
+    blocks = np.stack([blocks] * 3, -1)
+    blocks[::7, ::5] ^= 255
+    for frame, ini, mn in ((noise, 3, 1), (noise, 40, 2), (blocks, 20, 7), (blocks, 250, 200)):
+        c = pkg.Context(width=320, height=240, n_levels=4, ini_fast_thr=ini, min_fast_thr=mn, min_node_area=50, max_keypoints=32768,
+                        max_candidates=65536)
+        p = orc.params(n_levels=4, ini_fast_thr=ini, min_fast_thr=mn, min_size=50)
+        got = c.detect(frame, max_out=32768)
+        ref = orc.detect(frame, p)
+        assert_same_detection(got, ref)
+        c.close()
+    assert len(ref["xy"]) >= 0
+
+
 def test_quadtree_storage_forms(pkg, orc):
     """k_quadtree / k_quadtree_big pick where the working arrays of a (level, frame) live from its candidate count N and the
     length n of its node list: N <= 2048 all in LDS; levels of images above 400 k pixels with N <= 12288: node arrays in
