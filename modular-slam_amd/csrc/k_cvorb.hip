@@ -130,18 +130,18 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
     __shared__ __attribute__((aligned(16))) uint8_t tile[72 * kSP];
     __shared__ __attribute__((aligned(16))) uint8_t sc[66 * kSc];
     __shared__ __attribute__((aligned(4))) uint16_t list[66 * 66 + 2]; // (at most every scored pixel survives: 20.1 KB in all, eight workgroups per CU)
-    constexpr uint32_t kDump = 66 * 66; // write-only slot for rejected pixels
     __shared__ uint32_t n_list;
 
-    // XCD-aware mapping (as k_fast_cells): all tiles of a frame get ids with the same (id & 7) and meet in one L2
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int f_local = (slot / n_tiles) * 8 + xcd;
+    // XCD-aware mapping (as k_fast_cells): all tiles of a frame get ids with the same (id & 7) and meet in one L2.  Grid:
+    // x = tile column * 8 + XCD, y = tile row, z = group of 8 frames (no divisions: two runtime divisions per wave were
+    // a tenth of the kernel's vector instructions)
+    const int xcd = blockIdx.x & 7;
+    const int f_local = (int)blockIdx.z * 8 + xcd;
     if(f_local >= n_frames)
         return;
-    const int t_id = slot % n_tiles;
     const LevelGeom& lv = g.lv[level];
     const int w = lv.w, h = lv.h, pitch = lv.pitch;
-    const int tx = t_id % tiles_x, ty = t_id / tiles_x;
+    const int tx = (int)(blockIdx.x >> 3), ty = (int)blockIdx.y;
     const int X0 = tx * 64, Y0 = ty * 64; // the tile's own block; scores cover (X0-1, Y0-1) + 66x66, pixels (X0-4, Y0-4) + 72x72
     const size_t frame = (size_t)f_local + g.frame0;
     const uint8_t* src = pyr + frame * g.slab + lv.offset;
@@ -181,6 +181,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         const int r_lo = max(0, 4 - Y0), r_hi = min(66, h - 3 - (Y0 - 1));
         // (only the items of rows below r_hi: the tiles of a level's last tile row are partly outside FAST's frame)
         const int i_end = min(66, r_hi) * 18;
+        uint16_t* seg = reinterpret_cast<uint16_t*>(sc) + (tid >> 6) * 320; // <= 5 rounds x 64 records
+        uint32_t n_grp = 0;                                                  // (wave-uniform)
         for(int i0 = (r_lo * 18) & ~255; i0 < i_end; i0 += 256)
         {
             const int i = i0 + tid;
@@ -208,36 +210,47 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
                                     (__builtin_amdgcn_lerp(q4, kd, 0u) & __builtin_amdgcn_lerp(q12, kd, 0u));
                 keep = (br | ~nd) & colmask;
             }
-            // compaction: wave-wide inclusive scan of the per-lane counts with DPP adds, one LDS atomic per wave
-            const uint32_t cnt = (uint32_t)__popc(keep);
-            uint32_t inc = cnt;
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true); // row_shr:1
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true); // row_shr:2
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xE, true); // row_shr:4
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xC, true); // row_shr:8
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xA, 0xF, true); // row_bcast:15
-            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xC, 0xF, true); // row_bcast:31
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            if(tot != 0)
+            // compaction as in k_fast_cells: ONE ballot per round on "the quad has a flag"; a surviving quad leaves a 16-bit
+            // record (item index << 4 | its four flags) in the wave's own segment, expanded to pixels below.  The segments
+            // (<= 5 rounds x 64 records x 2 bytes per wave) live in the first 2560 bytes of the score map, which the waves
+            // clear again when they are through with them.
+            const bool any = keep != 0;
+            const unsigned long long vote = __ballot(any);
+            if(any)
             {
-                uint32_t base = 0;
-                if(lane == 0)
-                    base = atomicAdd(&n_list, tot);
-                base = __builtin_amdgcn_readfirstlane(base);
-                uint32_t pos2 = 2u * (base + inc - cnt); // byte offset into list[]
-                const uint32_t dump2 = 2u * kDump;
-                const uint32_t yx = (uint32_t)(((r + 3) << 8) | (4 * q)); // (tile row, tile column) of the quad's pixel 0
-#pragma unroll
-                for(int j = 0; j < 4; ++j)
-                {
-                    const int m = __builtin_amdgcn_sbfe((int)keep, 8 * j + 7, 1); // -1 when kept
-                    uint32_t slot2;
-                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(slot2) : "v"(m), "v"(pos2), "v"(dump2));
-                    *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(list) + slot2) = (uint16_t)(yx + j);
-                    pos2 = (uint32_t)__mul24(m, -2) + pos2;
-                }
+                const uint32_t nib = ((((keep >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+                seg[n_grp + __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u))] =
+                    (uint16_t)(((uint32_t)i << 4) | nib);
             }
+            n_grp += (uint32_t)__popcll(vote);
         }
+        for(uint32_t g0 = 0; g0 < n_grp; g0 += 64)
+        {
+            const uint32_t rec = g0 + lane < n_grp ? (uint32_t)seg[g0 + lane] : 0u;
+            const bool f0 = (rec & 1u) != 0, f1 = (rec & 2u) != 0, f2 = (rec & 4u) != 0, f3 = (rec & 8u) != 0;
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3);
+            uint32_t base = 0;
+            if(lane == 0)
+                base = atomicAdd(&n_list, c0 + c1 + c2 + c3);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t it = rec >> 4;
+            const uint32_t rr = (it * 3641u) >> 16, qq = it - rr * 18u;          // item -> (scored row, tile dword)
+            const uint32_t yx = ((rr + 3u) << 8) | (4u * qq);                     // (tile row, tile column) of the quad's pixel 0
+            if(f0)
+                list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint16_t)yx;
+            base += c0;
+            if(f1)
+                list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint16_t)(yx + 1);
+            base += c1;
+            if(f2)
+                list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u))] = (uint16_t)(yx + 2);
+            base += c2;
+            if(f3)
+                list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, 0u))] = (uint16_t)(yx + 3);
+        }
+        for(int z = lane; z < 160; z += 64) // the wave's segment is score map again
+            reinterpret_cast<uint32_t*>(seg)[z] = 0u;
     }
     __syncthreads();
     const uint32_t n = n_list;
@@ -248,9 +261,8 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         const int ay = (int)(ca >> 8), ax = (int)(ca & 0xFF), by = (int)(cb >> 8), bx = (int)(cb & 0xFF);
         const uint8_t* pa = &tile[ay * kSP + kSX + ax];
         const uint8_t* pb = &tile[by * kSP + kSX + bx];
-        const uint32_t vv = ((uint32_t)pa[0] + kArcBias) | (((uint32_t)pb[0] + kArcBias) << 16);
-        uint32_t e[16];
-#define MSLAM_E(k, off) e[k] = vv - ((uint32_t)pa[off] | ((uint32_t)pb[off] << 16))
+        uint32_t e[16]; // circle pixel k of both candidates side by side (raw pixels: arc_score2_raw)
+#define MSLAM_E(k, off) e[k] = (uint32_t)pa[off] | ((uint32_t)pb[off] << 16)
         MSLAM_E(0, 3 * kSP);
         MSLAM_E(1, 3 * kSP + 1);
         MSLAM_E(2, 2 * kSP + 2);
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256) void k_fast_tiles(const uint8_t* __restrict__ 
         MSLAM_E(15, 3 * kSP - 1);
 #undef MSLAM_E
         int sa, sb;
-        arc_score2(e, sa, sb);
+        arc_score2_raw(e, (int)pa[0], (int)pb[0], sa, sb);
         if(sa >= thr && sa > 0)
             sc[(ay - 3) * kSc + (ax - 3)] = (uint8_t)sa;
         if(sb >= thr && sb > 0)
@@ -338,9 +350,9 @@ void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int thr, const C
     gg.frame0 = frame0;
     for(int l = 0; l < g.n_levels; ++l)
     {
-        const int tiles_x = (g.lv[l].w + 63) / 64, n_tiles = tiles_x * ((g.lv[l].h + 63) / 64);
-        const unsigned grid = (unsigned)((n_frames + 7) / 8) * 8u * (unsigned)n_tiles;
-        hipLaunchKernelGGL(k_fast_tiles, dim3(grid), dim3(256), 0, s, d_pyr, gg, l, tiles_x, n_tiles, n_frames, thr, a);
+        const int tiles_x = (g.lv[l].w + 63) / 64, tiles_y = (g.lv[l].h + 63) / 64, n_tiles = tiles_x * tiles_y;
+        const dim3 grid(8u * (unsigned)tiles_x, (unsigned)tiles_y, (unsigned)((n_frames + 7) / 8));
+        hipLaunchKernelGGL(k_fast_tiles, grid, dim3(256), 0, s, d_pyr, gg, l, tiles_x, n_tiles, n_frames, thr, a);
     }
 }
 
