@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSLAM_HIP_ABI_VERSION 3
+#define MSLAM_HIP_ABI_VERSION 4
 
 enum
 {

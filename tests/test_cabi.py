@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.lib()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.mslam_hip_abi_version() == 3   # 2: mslam_hip_params gained detector / n_features / edge_threshold; 3: debug_counts takes its row count
+    assert lib.mslam_hip_abi_version() == 4   # 2: mslam_hip_params gained detector / n_features / edge_threshold; 3: debug_counts takes its row count;
+    # 4: + mslam_hip_pnp_set_confidence (the PnP entry points now end on the 0.99 confidence bound by default), mslam_hip_pack_batch_dev, mslam_hip_packed_capacity
 
 
 def test_default_params_are_the_reference_operating_point(pkg):
