@@ -210,44 +210,97 @@ def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
     }
 
 
+def host_cpu_share():
+    """What this process may actually use of the host: the affinity mask and the cgroup CPU quota (a container on a
+    256-thread host is usually given a fraction of it), plus the cgroup's throttling clock for before / after deltas."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    return affinity, quota
+
+
+def cgroup_throttled_s():
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for line in open(path):
+                k, v = line.split()[:2]
+                if k == "throttled_usec":
+                    return float(v) * 1e-6
+                if k == "throttled_time":
+                    return float(v) * 1e-9
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def cpu_baseline(frames, params_kw, seconds, cv=False, n_features=1000):
-    """Oracle (= port of the reference CPU plugin) detect + match on the host cores: one core, then all cores
-    (frames sharded over threads; the C oracle releases the GIL inside ctypes calls)."""
+    """Oracle (= port of the reference CPU plugin) detect + match on the host cores, timed by the C harness
+    oracle/mslam_cpu_bench.c: frames sharded over pthreads, one mso_detect + mso_match loop per thread, at least 8 frames
+    per thread — first one thread, then as many threads as this process may use (affinity mask, cgroup quota)."""
     import __graft_entry__ as graft
-    from concurrent.futures import ThreadPoolExecutor
     orc = graft.load_oracle()
     orc.lib()
-    cores = os.cpu_count() or 1
+    affinity, quota = host_cpu_share()
+    cores = max(1, min(affinity, int(np.ceil(quota)) if quota else affinity))
     if cv:
-        p = orc.cvorb_params(n_features=n_features, n_levels=params_kw["n_levels"])
-        detect = orc.cvorb_detect
+        p, cvp = None, orc.cvorb_params(n_features=n_features, n_levels=params_kw["n_levels"])
     else:
-        p = orc.params(**params_kw)
-        detect = orc.detect
-
-    def run(n, threads):
-        sample = [np.ascontiguousarray(frames[i % len(frames)]) for i in range(n)]
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(threads) as ex:
-            dets = list(ex.map(lambda i: detect(sample[i], p), range(n)))
-            list(ex.map(lambda i: orc.match(dets[i]["desc"], dets[i - 1]["desc"]), range(1, n)))
-        dt = time.perf_counter() - t0
-        return sum(len(d["xy"]) for d in dets) / dt, dt
-
-    # size the samples from a short probe so that the leg stays within its budget on any host
-    t0 = time.perf_counter()
-    d0 = detect(np.ascontiguousarray(frames[0]), p)
-    orc.match(d0["desc"], d0["desc"])
-    per_frame = max(time.perf_counter() - t0, 1e-3)
-    n1 = int(max(4, min(len(frames), 0.3 * seconds / per_frame)))
-    v1, dt1 = run(n1, 1)
-    nall = int(max(2 * cores, min(len(frames), 0.7 * seconds / per_frame * cores)))
-    vall, dtall = run(nall, cores)
-    return {"value": vall, "unit": "keypoints/s", "cores": cores, "kind": "port",
-            "value_1core": v1, "host_cpu_count": os.cpu_count(),
-            "sample": "the same synthetic stream, detect + knn-2 match vs previous frame, oracle/ C restatement "
-                      "(scalar; OpenCV's internal SIMD is not reproduced): %d frames on %d threads (%.1f s), "
-                      "%d frames on 1 thread (%.1f s)" % (nall, cores, dtall, n1, dt1)}
+        p, cvp = orc.params(**params_kw), None
+    sample = np.ascontiguousarray(frames[:min(len(frames), 64)])
+    # size the two legs from a short probe so that the whole leg stays within its budget on any host
+    probe = orc.bench_stream(sample, p, 1, 2, cv_params=cvp)
+    per_frame = max(probe["seconds"] / 2, 1e-3)
+    n1 = int(max(8, 0.3 * seconds / per_frame))
+    r1 = orc.bench_stream(sample, p, 1, n1, cv_params=cvp)
+    v1 = r1["keypoints"] / r1["seconds"]
+    # all threads: 8 frames per thread first; when that took less than 5 s, again with the block length that fills
+    # max(5 s, 0.7 x budget) at the rate the first run measured (a host that gives this process fewer cores than it
+    # shows stretches the wall time, not the budget)
+    per_thread = 8
+    thr0 = cgroup_throttled_s()
+    rall = orc.bench_stream(sample, p, cores, per_thread, cv_params=cvp)
+    thr1 = cgroup_throttled_s()
+    want = max(5.0, 0.7 * seconds)
+    for _ in range(3):
+        if rall["seconds"] >= 5.0:
+            break
+        per_thread = int(min(4096, max(per_thread + 1, np.ceil(1.1 * per_thread * want / max(rall["seconds"], 1e-3)))))
+        thr0 = cgroup_throttled_s()
+        rall = orc.bench_stream(sample, p, cores, per_thread, cv_params=cvp)
+        thr1 = cgroup_throttled_s()
+    vall = rall["keypoints"] / rall["seconds"]
+    eff = vall / (cores * v1)
+    out = {"value": vall, "unit": "keypoints/s", "cores": cores, "kind": "port", "value_1core": v1,
+           "scaling_efficiency": eff, "host_cpu_count": os.cpu_count(), "affinity_cpus": affinity,
+           "cgroup_cpu_quota": quota, "frames_per_thread": per_thread, "seconds_all_cores": rall["seconds"],
+           "thread_seconds_min_max": [rall["thread_seconds_min"], rall["thread_seconds_max"]],
+           "harness": "oracle/mslam_cpu_bench.c (pthreads, one detect + match loop per thread)",
+           "sample": "the same synthetic stream (%d distinct frames, taken cyclically), detect + knn-2 match vs the "
+                     "previous frame, oracle/ C restatement (scalar, -O2 -mpopcnt; OpenCV's internal SIMD is not "
+                     "reproduced): %d frames on %d threads (%.1f s), %d frames on 1 thread (%.1f s)"
+                     % (len(sample), rall["frames"], cores, rall["seconds"], n1, r1["seconds"])}
+    if thr0 is not None and thr1 is not None:
+        out["cgroup_throttled_s_during_all_cores"] = thr1 - thr0
+    if eff < 0.3:
+        # a thread's loop takes per_thread x per_frame seconds when it has a core to itself
+        slow = rall["thread_seconds_max"] / max(per_thread * (r1["seconds"] / n1), 1e-9)
+        why = "the slowest thread's loop took %.1fx the one-thread time per frame" % slow
+        if out.get("cgroup_throttled_s_during_all_cores", 0) > 0.05 * rall["seconds"]:
+            why += "; the cgroup throttled this process for %.1f s of CPU time during the leg (CPU quota)" % (thr1 - thr0)
+        elif quota is None and affinity >= (os.cpu_count() or 1):
+            why += "; no cgroup quota or affinity limit is visible, so the threads share cores with other tenants of " \
+                   "the host or are bound by its memory system"
+        out["binds_scaling"] = why
+    return out
 
 
 def dry_run(a, rank, world):

@@ -164,6 +164,13 @@ int mso_bow_vector(const mso_voc* v, const uint8_t* desc, int n, uint32_t* words
 /* DBoW3 L1Scoring::score (published algorithm; not in the reference tree) */
 double mso_bow_score_l1(const uint32_t* w1, const double* v1, int n1, const uint32_t* w2, const double* v2, int n2);
 
+/* ---- the timed CPU leg (mslam_cpu_bench.c): n_threads pthreads, each one mso_detect + mso_match loop over its own block
+ * of frames_per_thread frames of the stream (rgbd_feature_frontend.cpp:187,237: detect, then match against the previous
+ * frame).  cvp non-NULL selects the cv::ORB detector mode.  out[5] = keypoints, matches, wall seconds, shortest and
+ * longest thread loop.  Returns 0, -1 when a frame exceeded max_kp, -2 when the threads could not be started. */
+int mso_bench_stream(const uint8_t* frames, int n_unique, int W, int H, const mso_orb_params* p,
+                     const mso_cvorb_params* cvp, int n_threads, int frames_per_thread, int max_kp, double out[5]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -354,3 +354,21 @@ def bow_score_l1(w1, v1, w2, v2):
     v1 = np.ascontiguousarray(v1, np.float64)
     v2 = np.ascontiguousarray(v2, np.float64)
     return lib().mso_bow_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))
+
+
+def bench_stream(frames, p, n_threads, frames_per_thread, cv_params=None, max_kp=32768):
+    """The timed CPU leg (mslam_cpu_bench.c): `n_threads` pthreads, each a detect + match-vs-previous-frame loop over
+    its own block of `frames_per_thread` frames of `frames` (n, H, W, 3) taken cyclically.  Returns a dict with the
+    keypoints and matches produced, the wall time and the shortest / longest thread loop."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, H, W = frames.shape[:3]
+    out = (C.c_double * 5)()
+    rc = lib().mso_bench_stream(_p(frames), n, W, H, C.byref(p) if cv_params is None else None,
+                                C.byref(cv_params) if cv_params is not None else None, int(n_threads),
+                                int(frames_per_thread), int(max_kp), out)
+    if rc == -2:
+        raise RuntimeError("oracle bench_stream: could not start %d threads" % n_threads)
+    if rc != 0:
+        raise RuntimeError("oracle bench_stream: a frame exceeded %d keypoints" % max_kp)
+    return {"keypoints": out[0], "matches": out[1], "seconds": out[2], "thread_seconds_min": out[3],
+            "thread_seconds_max": out[4], "threads": int(n_threads), "frames": int(n_threads) * int(frames_per_thread)}
