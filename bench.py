@@ -154,6 +154,8 @@ def parse():
     ap.add_argument("--pnp", action="store_true",
                     help="also estimate the frame-to-frame pose of every frame in the step (batched RANSAC PnP on the "
                          "matches + back-projected points: mslam_hip_pnp_batch_dev)")
+    ap.add_argument("--exchange-granularity", default="batch", choices=["batch", "frame"],
+                    help="loop-candidate exchange: one all-gather per batch (16 KB x frames per rank) or one per frame (16 KB per rank)")
     ap.add_argument("--extras-timeout", type=int, default=300,
                     help="with several ranks: seconds the legs after the timed region may take before rank 0 prints "
                          "the line without them")
@@ -406,7 +408,7 @@ def main():
             # reallocation + copy of the posting log) falls into the timed steps
             # (at most 2^31 / max_keypoints entries are addressable; beyond the reservation the storage doubles as usual)
             ctx.bow_db_reserve(min((max(a.warmup, n_batches) + 3 * a.steps + 16) * B, (1 << 31) // ctx.params.max_keypoints - 1))
-        cross = CrossStreamLoopCandidates(k_max=2048 * k_scale)
+        cross = CrossStreamLoopCandidates(k_max=2048 * k_scale, granularity=a.exchange_granularity)
 
     def step(i, bow=a.bow):
         off = (i % n_batches) * B
@@ -559,11 +561,23 @@ def main():
                     "stages_ms_per_launch": {k: round(x, 4) for k, x in avg.items()},
                     "stages_ms_per_step": {k: round(x, 4) for k, x in acc.items()},
                     "stages_gbs": {k: round(sb[k] / (x * 1e-3) / 1e9, 1) for k, x in acc.items() if x > 0 and k in sb}}
+        w, h, _ = ctx.level_geometry()
+        P = sum(x * y for x, y in zip(w, h))
+        extract_bytes = 3 * a.width * a.height + 2 * P + 48 * (kp_b / B)
         st_prof, fps_prof, _ = pmc_profile()
         if st_prof is not None:
             roofline["traffic_MB_per_frame"] = round(sum(
                 (2 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024 for d in st_prof.values()) / fps_prof / 1e6, 2)
             roofline["stages_valu_issue_ms"] = {k: round(valu_issue_ms(k, B), 3) for k in acc if k in st_prof}
+        # the whole step against the fused-ideal figure: how much of the memory-side traffic is re-reads / re-writes of planes
+        # between the kernels of the chain (counter traffic from the committed PMC passes, when they match these sources)
+        ws = {"algorithmic_MB_per_frame": round(extract_bytes / 1e6, 3),
+              "counter_MB_per_frame": roofline.get("traffic_MB_per_frame"),
+              "what": "SURVEY.md §8d fused-ideal bytes (3WH + 2P + 48K) vs (2 x FETCH_SIZE + WRITE_SIZE) of every kernel of the step"}
+        ws["ratio"] = round(ws["counter_MB_per_frame"] / ws["algorithmic_MB_per_frame"], 2) if ws["counter_MB_per_frame"] else None
+        if ws["counter_MB_per_frame"] is None:
+            ws["counter_note"] = traffic_note
+        roofline["whole_step"] = ws
         if "stages_ms_serialized" in extras:
             roofline["stages_ms_serialized"] = extras.pop("stages_ms_serialized")
         if "match_knn2" in acc:
@@ -582,9 +596,6 @@ def main():
             roofline["match_valu"] = {"bound": "valu-issue", "ops_per_pair": 34 / 16, "achieved": round(tops, 2),
                                       "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tlane-op/s",
                                       "frac": round(tops / VALU_PEAK_TOPS, 3)}
-        w, h, _ = ctx.level_geometry()
-        P = sum(x * y for x, y in zip(w, h))
-        extract_bytes = 3 * a.width * a.height + 2 * P + 48 * (kp_b / B)
         extract_gbs = extract_bytes * a.steps * B * world / dt_max / 1e9
         roofline["extract_fused_ideal"] = {
             "bytes_per_frame": int(extract_bytes), "achieved_GBps_per_gpu": round(extract_gbs / world, 1),
@@ -597,7 +608,9 @@ def main():
             "unit": "keypoints/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %dx%d RGB-D stream, %d-level ORB (reference defaults 1.2/20/7, min-area %d), "
+            "config": {"workload": "%s: synthetic %dx%d RGB-D stream, device-resident frames (RGB + depth in HBM when the timed "
+                                   "region starts; the PCIe-inclusive rate is `value_pcie_inclusive`), %d-level ORB (reference "
+                                   "defaults 1.2/20/7, min-area %d), "
                                    "extract + BF-Hamming knn-2 match (ratio 0.7) vs previous frame + depth back-projection%s%s" % (
                            cfg, a.width, a.height, a.levels, a.min_area,
                            " + RANSAC PnP (100 hypotheses, 5 px) of every frame against its predecessor" if a.pnp else "",
@@ -618,6 +631,9 @@ def main():
         if "value_popcount_matcher" in extras:
             extras["popcount_match_kernel"] = POPCOUNT_KERNEL
         out.update(extras)
+        if "pcie_inclusive" in out:
+            # the same step fed from page-locked host memory and with its results copied back: never `value`
+            out["value_pcie_inclusive"] = out["pcie_inclusive"]["keypoints_per_s"]
         if with_cpu and not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, dict(n_levels=a.levels, min_size=a.min_area), a.cpu_seconds, cv,
                                                a.n_features)
@@ -643,8 +659,10 @@ def main():
 
     # the fallback line is a snapshot of the headline taken NOW, on the main thread, before any extra leg runs: the
     # watchdog thread only copies it, it never calls into the context or reads `extras` while the main thread works on them
-    headline = make_line({}, with_cpu=False) if (world > 1 and rank == 0) else None
-    if world > 1:
+    # (also armed for --rccl-world1: its collective is a real RCCL call, and a hung one must end the run non-zero)
+    armed = world > 1 or a.rccl_world1
+    headline = make_line({}, with_cpu=False) if (armed and rank == 0) else None
+    if armed:
         def give_up():
             # a collective / GPU step after the timed region never completed: that is a hang, not a pass.  Rank 0 still
             # prints the headline (the timed region was complete) with the reason, and EVERY rank exits non-zero.
@@ -702,8 +720,10 @@ def main():
                     "what": "per batch: DBoW3 vectors of %d frames (k=10 L=%d vocabulary) -> pack -> ONE "
                             "all_gather_into_tensor -> L1 scores of own frame t vs frame t of every stream" % (B, a.voc_levels),
                     "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                    "granularity": cross.granularity,
                     "collectives_per_batch": (cross.collectives - c0) / float(n_ex),
                     "bytes_per_rank_per_batch": 4 * set_dwords(B, cross.k_max),
+                    "bytes_per_rank_per_collective": cross.bytes_per_collective,
                     "ms_per_batch_incl_bow": float(t_ex.item()) / n_ex * 1e3,
                     "self_score_min": float(s_host[:, rank].min()),
                     "cross_score_max": float(np.delete(s_host, rank, 1).max())}
@@ -956,6 +976,21 @@ def main():
                                       if (a.rccl_world1 and dist.is_initialized()) else "world 1: a device copy of the set",
                                       "what": "mslam_hip_bow_pack_dev -> all_gather_into_tensor -> "
                                               "mslam_hip_bow_cross_score_packed_dev on the communication stream"}
+                    # the same exchange at frame granularity (one collective of 2 k_max + 1 dwords per frame): same wire format,
+                    # same scores; what a live rig whose batch is one frame pays per frame
+                    n_fr = B4  # (the pack kernel writes the whole last batch)
+                    cross4f = CrossStreamLoopCandidates(k_max=2048, always_collective=a.rccl_world1, granularity="frame")
+                    cross4f.step_gpu(ctx4, ts4, n_fr)
+                    cross4f.finish(ts4)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(4):
+                        cross4f.step_gpu(ctx4, ts4, n_fr)
+                    cross4f.finish(ts4)
+                    torch.cuda.synchronize()
+                    l4["exchange_per_frame"] = {"bytes_per_collective": cross4f.bytes_per_collective, "frames": n_fr,
+                                                "collectives_per_frame": (cross4f.collectives / 5.0) / n_fr,
+                                                "us_per_frame_alone": (time.perf_counter() - t0) / 4 / n_fr * 1e6}
                     extras["cfg4_one_rank"] = l4
                     ctx4.close()
                     del d4, dd4, f4

@@ -9,6 +9,13 @@ k_max = 2048 -> 16 KB per frame, and ONE `all_gather_into_tensor` per batch move
 is one collective: fewer, larger messages suit the point-to-point xGMI mesh).  Every rank then scores
 its frame t against frame t of every other stream from the gathered buffer alone.
 
+`granularity="frame"` is the other end of the trade: one collective PER FRAME, each moving one frame's set
+(`set_dwords(1, k_max)` dwords = 16 KB per rank at k_max = 2048, 128 KB gathered on 8 ranks — SURVEY.md §8e's
+per-frame exchange).  A frame's set is exactly the batch format for a batch of one frame, so both forms speak
+the same wire format and a frame-granular rank interoperates with nothing but itself being slower per byte: it
+is the form for a live rig whose "batch" is the frame that just arrived, where the exchange is latency-bound;
+the per-batch collective is the throughput form.  `split_set` / `join_sets` convert between the two layouts.
+
 GPU path (`step_gpu`): pack -> all-gather -> score are enqueued on a communication stream behind an
 event of the context's stream — no host synchronisation — so the collective of batch i overlaps the
 extraction of batch i+1; `finish()` joins the two streams.
@@ -61,8 +68,27 @@ def unpack_set(buf, n_frames, k_max):
             a[n_frames * k_max * 2:].copy())
 
 
+def split_set(batch_set, n_frames, k_max):
+    """a batch's set [set_dwords(n_frames)] -> its frames' sets [n_frames, set_dwords(1)] (frame t: its k_max (word, value)
+    pairs, then its count): each row is the wire format of a batch of one frame"""
+    vec = batch_set[:n_frames * 2 * k_max].view(n_frames, 2 * k_max)
+    cnt = batch_set[n_frames * 2 * k_max:].view(n_frames, 1)
+    return torch.cat([vec, cnt], dim=1).contiguous()
+
+
+def join_sets(frame_sets, k_max):
+    """gathered per-frame sets [n_frames, world, set_dwords(1)] -> the per-batch layout [world, set_dwords(n_frames)]"""
+    n_frames, world = frame_sets.shape[0], frame_sets.shape[1]
+    vec = frame_sets[:, :, :2 * k_max].permute(1, 0, 2).reshape(world, n_frames * 2 * k_max)
+    cnt = frame_sets[:, :, 2 * k_max].permute(1, 0)
+    return torch.cat([vec, cnt], dim=1).contiguous()
+
+
 class CrossStreamLoopCandidates:
-    def __init__(self, k_max=2048, group=None, always_collective=False):
+    def __init__(self, k_max=2048, group=None, always_collective=False, granularity="batch"):
+        if granularity not in ("batch", "frame"):
+            raise ValueError("granularity must be 'batch' (one collective per batch) or 'frame' (one per frame)")
+        self.granularity = granularity
         self.k_max = k_max
         self.group = group
         # world 1 normally short-cuts the gather to a device copy; always_collective issues the collective anyway (what a
@@ -74,11 +100,27 @@ class CrossStreamLoopCandidates:
         self._bufs = {}        # (n_frames, slot) -> (local set, gathered sets, scores)
         self._slot = 0
         self._pack_done = None
-        self.collectives = 0   # all-gathers issued (one per batch)
+        self.collectives = 0   # all-gathers issued (one per batch, or one per frame with granularity="frame")
+        self.bytes_per_collective = 0  # payload each rank contributed to the last collective
 
     # ---- the exchange step -------------------------------------------------------------------
-    def all_gather_sets(self, local_set, out=None):
-        """ONE collective per batch: local_set int32 [set_dwords] -> int32 [world, set_dwords]"""
+    def all_gather_sets(self, local_set, out=None, n_frames=None):
+        """The exchange of one batch: local_set int32 [set_dwords(n_frames)] -> int32 [world, set_dwords(n_frames)].
+        granularity "batch": ONE collective; "frame" (needs n_frames): one collective per frame, each moving that
+        frame's set_dwords(1) dwords; the result is put back into the per-batch layout, so callers see no difference."""
+        if self.granularity == "frame" and n_frames is not None and n_frames > 1:
+            mine = split_set(local_set, n_frames, self.k_max)                         # [B, 2 k_max + 1]
+            got = torch.empty((n_frames, self.world, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+            for t in range(n_frames):
+                self._all_gather_one(mine[t], got[t])
+            joined = join_sets(got, self.k_max)
+            if out is None:
+                return joined
+            out.copy_(joined)
+            return out
+        return self._all_gather_one(local_set, out)
+
+    def _all_gather_one(self, local_set, out=None):
         if out is None:
             out = torch.empty((self.world, local_set.numel()), dtype=local_set.dtype, device=local_set.device)
         if self.world > 1 and local_set.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -92,6 +134,7 @@ class CrossStreamLoopCandidates:
         else:
             out[0].copy_(local_set)
         self.collectives += 1
+        self.bytes_per_collective = local_set.numel() * local_set.element_size()
         return out
 
     # ---- GPU path: vectors come straight out of the context's BoW view --------------------------
@@ -120,7 +163,7 @@ class CrossStreamLoopCandidates:
         ctx.bow_pack_dev(self.k_max, local.data_ptr())            # on the context's stream
         self._comm.wait_stream(ctx_stream)
         with torch.cuda.stream(self._comm):
-            self.all_gather_sets(local, gathered)
+            self.all_gather_sets(local, gathered, n_frames)
             ctx.bow_cross_score_packed_dev(gathered.data_ptr(), self.world, self.rank, n_frames, self.k_max,
                                            scores.data_ptr(), stream=self._comm.cuda_stream)
         return scores
@@ -137,7 +180,7 @@ class CrossStreamLoopCandidates:
         """words/values/counts as in pack_vectors (CPU tensors); scorer(w1, v1, w2, v2) -> float is applied to the
         vectors exactly as transmitted (f32 values widened to f64)."""
         B = words.shape[0]
-        sets = self.all_gather_sets(pack_vectors(words, values, counts, self.k_max))
+        sets = self.all_gather_sets(pack_vectors(words, values, counts, self.k_max), n_frames=B)
         un = [unpack_set(sets[r], B, self.k_max) for r in range(self.world)]
         mw, mv, mn = un[self.rank]
         out = np.zeros((B, self.world))

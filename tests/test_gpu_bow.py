@@ -109,51 +109,61 @@ def test_bow_batch_device(pkg, orc, synth_frames):
 def test_rccl_world1_exchange(pkg, orc, synth_frames):
     """what ONE GPU can exercise of the RCCL path (the 8-GPU run is the driver's): a process group on the
     `nccl` backend (= RCCL on ROCm) with a single rank, the exchange step's all_gather_into_tensor issued as a real
-    collective on the communication stream (always_collective), self-scores against the oracle.  Runs in a child
-    process with a time limit: a box whose RCCL cannot initialise must not hang the suite (then the test is skipped)."""
+    collective on the communication stream (always_collective), self-scores against the oracle — per batch and per frame.
+    Runs in a child process with a time limit.  ONLY a torch build without the nccl backend skips; a timeout (the child is
+    killed), a fault, an abort or any other non-zero exit FAILS with the child's stderr tail."""
     import subprocess
     import textwrap
     code = textwrap.dedent("""
         import os, sys, socket, numpy as np, torch, torch.distributed as dist
+        if not dist.is_nccl_available():
+            print("RCCL_ABSENT"); sys.exit(0)
         sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
         import __graft_entry__ as g, synth
         pkg = g.load_package(); orc = g.load_oracle()
         from modular_slam_amd.multi_stream import CrossStreamLoopCandidates
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         torch.cuda.set_device(0)
+        print("RCCL_INIT_BEGIN", flush=True)
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
+        print("RCCL_INIT_OK", flush=True)
         blob = synth.make_vocabulary(10, 3)
         V = orc.Vocabulary(blob)
         frames = synth.make_stream(3, 640, 480, seed=1234)
         ts = torch.cuda.Stream()
         c = pkg.Context(width=640, height=480, max_batch=3, max_keypoints=4096, stream=ts.cuda_stream)
         c.bow_load(blob)
-        x = CrossStreamLoopCandidates(k_max=2048, always_collective=True)
         dev = torch.from_numpy(frames).cuda()
-        for rep in range(3):
-            c.detect_batch_dev(dev.data_ptr(), 3)
-            c.bow_batch_dev(False)
-            sc = x.step_gpu(c, ts, 3)
-        x.finish(ts); c.sync()
-        sc = sc.cpu().numpy()
-        for t in range(3):
-            w, v = V.bow_vector(orc.detect(frames[t], orc.params())["desc"])
-            v = v.astype(np.float32).astype(np.float64)
-            assert sc[t, 0] == orc.bow_score_l1(w, v, w, v), t
-        assert x.collectives == 3 and dist.get_backend() == "nccl"
+        for gran, per_batch in (("batch", 1), ("frame", 3)):
+            x = CrossStreamLoopCandidates(k_max=2048, always_collective=True, granularity=gran)
+            for rep in range(3):
+                c.detect_batch_dev(dev.data_ptr(), 3)
+                c.bow_batch_dev(False)
+                sc = x.step_gpu(c, ts, 3)
+            x.finish(ts); c.sync()
+            sc = sc.cpu().numpy()
+            for t in range(3):
+                w, v = V.bow_vector(orc.detect(frames[t], orc.params())["desc"])
+                v = v.astype(np.float32).astype(np.float64)
+                assert sc[t, 0] == orc.bow_score_l1(w, v, w, v), (gran, t)
+            assert x.collectives == 3 * per_batch and dist.get_backend() == "nccl", (gran, x.collectives)
+            print("RCCL_GRANULARITY_OK", gran, x.bytes_per_collective, flush=True)
         dist.barrier(); dist.destroy_process_group(); c.close()
         print("RCCL_WORLD1_OK")
     """ % (ROOT, ROOT))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
-    except subprocess.TimeoutExpired:
-        pytest.skip("RCCL did not initialise within 240 s on this box")
-    if "RCCL_WORLD1_OK" not in r.stdout:
-        if "AssertionError" in r.stderr:
-            raise AssertionError(r.stderr[-2000:])
-        pytest.skip("no usable RCCL on this box: " + r.stderr[-400:].replace("\n", " | "))
+    except subprocess.TimeoutExpired as e:  # subprocess.run has killed the child
+        def _txt(b):
+            return (b.decode("utf-8", "replace") if isinstance(b, bytes) else (b or ""))[-1500:]
+        pytest.fail("the RCCL world-1 exchange did not finish within 240 s (child killed): stdout %r stderr %r" % (
+            _txt(e.stdout), _txt(e.stderr)))
+    if "RCCL_ABSENT" in r.stdout:
+        pytest.skip("this torch build has no nccl (RCCL) backend")
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, "exit code %s\nstdout: %s\nstderr: %s" % (
+        r.returncode, r.stdout[-600:], r.stderr[-2000:])
 
 
 def test_cross_stream_scores(pkg, orc, synth_frames):
