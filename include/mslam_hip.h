@@ -277,8 +277,10 @@ int mslam_hip_get_points_view(mslam_hip_ctx* ctx, mslam_hip_points_view* view);
  * back, into `out`: device memory (follow with ONE copy of header.bytes) or page-locked, device-mapped host memory (the
  * kernel's stores are the transfer; read the header after synchronising).  Frame t's keypoints are records
  * kp_offset[t] .. kp_offset[t+1]-1 of every keypoint array, its matches records match_offset[t] .. match_offset[t+1]-1
- * (match indices are relative to the frame, as in the views).  If the results do not fit capacity_bytes, header.fits is 0,
- * header.bytes tells what was needed, nothing else is written and mslam_hip_sync reports MSLAM_HIP_E_CAPACITY.
+ * (match indices are relative to the frame, as in the views).  A batch that mslam_hip_match_batch_dev has not run on is packed
+ * with zero matches (never with an older batch's pairs).  If the results do not fit capacity_bytes, header.fits is 0,
+ * header.bytes tells what was needed, no record is written (the two offset tables still are when they fit) and
+ * mslam_hip_sync reports MSLAM_HIP_E_CAPACITY.
  * mslam_hip_packed_capacity: an upper bound for n_frames frames (every frame at max_keypoints). */
 typedef struct
 {
@@ -303,7 +305,8 @@ size_t mslam_hip_packed_capacity(const mslam_hip_ctx* ctx, int n_frames, int wit
  * The minimal solver, sampling and refinement are this library's own (P3P, splitmix64 with `seed`, damped
  * Gauss-Newton): see csrc/k_pnp.hip for what is and is not the same as OpenCV's internals.  The call site's confidence
  * (0.99, :57) ends the loop as in OpenCV's RANSACPointSetRegistrator: every new best hypothesis lowers the iteration
- * count to log(1 - confidence) / log(1 - w^4) (w = its inlier share), hypotheses beyond it are not looked at. */
+ * count to log(1 - confidence) / log(1 - w^5) (w = its inlier share; 5 = the model points cv::solvePnPRansac samples for this
+ * call's flags, although this library's own minimal sample is 3 + 1 points), hypotheses beyond it are not looked at. */
 int mslam_hip_pnp_ransac(mslam_hip_ctx* ctx, const float* object_points, const float* image_points, int n, double fx,
                          double fy, double cx, double cy, int use_extrinsic_guess, int iterations,
                          double reprojection_error, uint64_t seed, double* rvec, double* tvec, uint8_t* inliers,

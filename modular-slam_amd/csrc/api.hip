@@ -382,6 +382,8 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
         (void)hipHostFree(c->h_out);
     if(c->h_hm)
         (void)hipHostFree(c->h_hm);
+    if(c->match_graph)
+        (void)hipGraphExecDestroy(c->match_graph);
     for(auto& e : c->detect_graph)
         if(e)
             (void)hipGraphExecDestroy(e);
@@ -653,6 +655,18 @@ static int create_impl(mslam_hip_ctx* c)
     HIPCHK(c, hipMemset(c->d_flags, 0, 4));
     if(has_detector)
     {
+    {
+        // the FAST score kernels order f16 denormal bit patterns (arc_score.hpp): checked once, on the device, in this build
+        uint32_t ok = 0;
+        launch_denorm_selfcheck(c->d_flags, c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&ok, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemset(c->d_flags, 0, 4));
+        if(ok != 1u)
+            return fail(c, MSLAM_HIP_E_RUNTIME, "v_pk_minimum3_f16 / v_pk_maximum3_f16 do not preserve f16 denormals in this build "
+                                                "(the FAST score kernels need .amdhsa_float_denorm_mode_16_64 3): refusing to run");
+    }
     HIPCHK(c, dmalloc(c->d_stage, (size_t)p.width * p.height * 3));
     // + 64: the patch loads of k_describe may run a few bytes past the last row of the last frame
     HIPCHK(c, dmalloc(c->d_pyr, B * g.slab + 256));
@@ -1090,6 +1104,8 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
                 a.sel_resp = reinterpret_cast<const float*>(c->quad.best);
                 a.cv_mode = 1;
             }
+            if(c->mirror_results && n_frames == 1)
+                a.h_mirror = c->d_h_out;
             launch_describe(g, a, f0, nf, cs);
         }
         if(n_chunks > 1)
@@ -1193,7 +1209,17 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     uint8_t* h_oct = h_desc + K * 32;
     uint8_t* h_ang = h_oct + K * 4;
     uint8_t* h_resp = h_ang + K * 4;
+    // (MSLAM_HIP_MIRROR_RESULTS=0: the packing kernel of round 3 instead of k_describe's own stores into the mapped block)
+    static const bool mirror_env = [] { const char* e = getenv("MSLAM_HIP_MIRROR_RESULTS"); return !e || atoi(e) != 0; }();
+    struct MirrorScope
+    {
+        mslam_hip_ctx* c;
+        MirrorScope(mslam_hip_ctx* cc, bool on) : c(cc) { c->mirror_results = on; }
+        ~MirrorScope() { c->mirror_results = false; }
+    } mirror_scope(c, mirror_env);
     auto enqueue_results = [&]() -> int {
+        if(c->mirror_results)
+            return MSLAM_HIP_OK;
         hipLaunchKernelGGL(k_pack_results, dim3(32), dim3(256), 0, c->stream, c->d_xy + K * 2, c->d_desc + K * 32, c->d_octave + K,
                            c->d_angle + K, c->d_response + K, c->d_count + 1, c->d_flags, c->d_h_out, (int)K);
         HIPCHK(c, hipGetLastError());
@@ -1298,6 +1324,7 @@ int mslam_hip_match_batch_dev(mslam_hip_ctx* c, double ratio, int chain_previous
     const size_t K = (size_t)c->p.max_keypoints;
     const int first = (chain_previous && c->have_prev) ? 0 : 1; // first frame that has a predecessor
     const int n_pairs = c->n_last - first;
+    c->match_seq = c->detect_seq;
     // the matcher runs on its own stream behind the detect batch it reads, so the next detect batch can
     // start right away (with profiling on, everything stays on the context's stream)
     const bool own = c->overlap_match && !c->profiling;
@@ -1371,7 +1398,7 @@ static int host_match_prepare(mslam_hip_ctx* c, const uint8_t* from_desc, int n_
         c->h_hm = nullptr;
         c->d_h_hm = nullptr;
         c->hm_from_cap = c->hm_to_cap = 0;
-        HIPCHK(c, dmalloc(c->d_hm_from, (size_t)(from_cap + to_cap) * 32));
+        HIPCHK(c, dmalloc(c->d_hm_from, (size_t)(from_cap + to_cap) * 32 + 16)); // (+ 16: the captured form's counts ride behind the rows)
         HIPCHK(c, dmalloc(c->d_hm_out, (size_t)to_cap * 6 + 4));
         if(c->d_hm_partial)
             (void)hipFree(c->d_hm_partial);
@@ -1380,7 +1407,12 @@ static int host_match_prepare(mslam_hip_ctx* c, const uint8_t* from_desc, int n_
         // page-locked, device-mapped: [descriptor staging (from | to) | from_idx | to_idx | n_out] — the caller's
         // (pageable) descriptors are copied here by the CPU and go up in ONE asynchronous copy (two blocking pageable
         // copies cost 25 us of the 84 us call); the ratio kernel writes its compacted pairs straight into the block
-        const size_t bytes = (size_t)(from_cap + to_cap) * 32 + ((size_t)to_cap * 2 + 4) * 4;
+        const size_t bytes = (size_t)(from_cap + to_cap) * 32 + 16 + ((size_t)to_cap * 2 + 4) * 4;
+        if(c->match_graph)
+        {
+            (void)hipGraphExecDestroy(c->match_graph); // captured on the buffers just freed
+            c->match_graph = nullptr;
+        }
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_hm), bytes, hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_hm), c->h_hm, 0));
         c->hm_from_cap = from_cap;
@@ -1412,6 +1444,84 @@ static void host_match_args(mslam_hip_ctx* c, int n_from, int n_to, MatchArgs& m
     // (about 8 tiles each) and merged (k_match.hip)
     m.partial = c->d_hm_partial;
     m.n_slices = std::max(1, std::min(kHostMatchSlices, (n_from + 255) / 256));
+}
+
+// mslam_hip_match as ONE graph launch (descriptor upload, matcher, merge, ratio test): the single synchronous call is bound
+// by its launches, not by its kernels (three launches + a copy: ~17 us of host time for ~22 us of kernels).  What varies from
+// call to call — the two row counts — rides behind the descriptors in the upload (the kernels take their counts from device
+// words, as the batched path does), the launch shapes come from the staging capacities, the train rows sit at a fixed
+// offset: the graph captured once serves every call until the capacities or the matcher kind change.
+static int host_match_graph(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to, int* n_out,
+                            int32_t* from_idx, int32_t* to_idx)
+{
+    const size_t fcap = (size_t)c->hm_from_cap, tcap = (size_t)c->hm_to_cap;
+    uint8_t* h_cnt = c->h_hm + (fcap + tcap) * 32;
+    std::memcpy(c->h_hm, from_desc, (size_t)n_from * 32);
+    std::memcpy(c->h_hm + fcap * 32, to_desc, (size_t)n_to * 32);
+    const int32_t counts[4] = {n_from, n_to, 0, 0};
+    std::memcpy(h_cnt, counts, sizeof(counts));
+    int32_t* res_dev = reinterpret_cast<int32_t*>(c->d_h_hm + (fcap + tcap) * 32 + 16);
+    const int32_t* res = reinterpret_cast<const int32_t*>(c->h_hm + (fcap + tcap) * 32 + 16);
+    if(!c->match_graph || c->match_graph_from_cap != c->hm_from_cap || c->match_graph_to_cap != c->hm_to_cap ||
+       c->match_graph_kind != c->matcher_kind)
+    {
+        if(c->match_graph)
+            (void)hipGraphExecDestroy(c->match_graph);
+        c->match_graph = nullptr;
+        hipGraph_t graph = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        hipError_t e = hipMemcpyAsync(c->d_hm_from, c->h_hm, (fcap + tcap) * 32 + 16, hipMemcpyHostToDevice, c->stream);
+        const int32_t* d_cnt = reinterpret_cast<const int32_t*>(c->d_hm_from + (fcap + tcap) * 32);
+        MatchArgs m{};
+        m.from_desc = c->d_hm_from;
+        m.to_desc = c->d_hm_from + fcap * 32;
+        m.from_cnt = d_cnt;
+        m.to_cnt = d_cnt + 1;
+        m.cap = (int)tcap;
+        m.cap_from = (int)fcap;
+        m.idx0 = c->d_hm_out;
+        m.idx1 = c->d_hm_out + tcap;
+        m.dist0 = c->d_hm_out + 2 * tcap;
+        m.dist1 = c->d_hm_out + 3 * tcap;
+        m.popcount_only = c->matcher_kind == MSLAM_HIP_MATCHER_POPCOUNT;
+        m.partial = c->d_hm_partial;
+        m.n_slices = kHostMatchSlices;
+        RatioArgs r{};
+        r.idx0 = m.idx0;
+        r.dist0 = m.dist0;
+        r.dist1 = m.dist1;
+        r.from_cnt = m.from_cnt;
+        r.to_cnt = m.to_cnt;
+        r.cap = (int)tcap;
+        r.thr = c->d_ratio_thr;
+        r.from_idx = res_dev;
+        r.to_idx = res_dev + tcap;
+        r.n_out = res_dev + 2 * tcap;
+        if(launch_match_ratio_single(m, r, c->stream))
+            c->last_match_kernel = 1;
+        else
+        {
+            c->last_match_kernel = launch_match_knn2(m, 1, c->stream);
+            launch_ratio_compact(r, 1, c->stream);
+        }
+        const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+        HIPCHK(c, e);
+        HIPCHK(c, e2);
+        HIPCHK(c, hipGraphInstantiate(&c->match_graph, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        c->match_graph_from_cap = c->hm_from_cap;
+        c->match_graph_to_cap = c->hm_to_cap;
+        c->match_graph_kind = c->matcher_kind;
+        c->match_graph_kernel = c->last_match_kernel;
+    }
+    c->last_match_kernel = c->match_graph_kernel;
+    HIPCHK(c, hipGraphLaunch(c->match_graph, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int32_t n = res[2 * tcap];
+    std::memcpy(from_idx, res, (size_t)n * 4);
+    std::memcpy(to_idx, res + tcap, (size_t)n * 4);
+    *n_out = n;
+    return MSLAM_HIP_OK;
 }
 
 int mslam_hip_join_matcher(mslam_hip_ctx* c)
@@ -1476,9 +1586,22 @@ int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, cons
     int rc = upload_ratio_table(c, ratio);
     if(rc)
         return rc;
+    // the captured form: when the staging capacities are at most twice what this call needs (the upload always moves whole
+    // capacities) and the matrix-core kernel's train range holds them
+    static const bool graph_env = [] { const char* e = getenv("MSLAM_HIP_MATCH_GRAPH"); return !e || atoi(e) != 0; }();
+    if(graph_env && c->use_graph && !c->profiling && !c->inplace_timing && c->hm_from_cap >= n_from && c->hm_to_cap >= n_to &&
+       c->hm_from_cap + c->hm_to_cap <= 2 * (n_from + n_to) + 2048 && c->hm_from_cap <= 32736)
+        return host_match_graph(c, from_desc, n_from, to_desc, n_to, n_out, from_idx, to_idx);
     rc = host_match_prepare(c, from_desc, n_from, to_desc, n_to);
     if(rc)
         return rc;
+    if(graph_env && c->use_graph && !c->profiling && !c->inplace_timing && c->hm_from_cap <= 32736 &&
+       c->hm_from_cap + c->hm_to_cap <= 2 * (n_from + n_to) + 2048)
+    {
+        // (first call / the buffers have just grown: the plain path's copy is queued — let it drain, then take the captured form)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return host_match_graph(c, from_desc, n_from, to_desc, n_to, n_out, from_idx, to_idx);
+    }
     MatchArgs m;
     host_match_args(c, n_from, n_to, m);
     c->last_match_kernel = launch_match_knn2(m, 1, c->stream);
@@ -1492,8 +1615,8 @@ int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, cons
     r.cap = n_to;
     r.thr = c->d_ratio_thr;
     // the compacted pairs and their count land in the mapped host block (they are small: 8 bytes per match)
-    int32_t* res_dev = reinterpret_cast<int32_t*>(c->d_h_hm + (size_t)(c->hm_from_cap + c->hm_to_cap) * 32);
-    const int32_t* res = reinterpret_cast<const int32_t*>(c->h_hm + (size_t)(c->hm_from_cap + c->hm_to_cap) * 32);
+    int32_t* res_dev = reinterpret_cast<int32_t*>(c->d_h_hm + (size_t)(c->hm_from_cap + c->hm_to_cap) * 32 + 16);
+    const int32_t* res = reinterpret_cast<const int32_t*>(c->h_hm + (size_t)(c->hm_from_cap + c->hm_to_cap) * 32 + 16);
     r.from_idx = res_dev;
     r.to_idx = res_dev + cap;
     r.n_out = res_dev + 2 * cap;

@@ -115,6 +115,9 @@ struct ResizeColArgs
 void launch_resize_col(const ResizeColArgs& a, hipStream_t s);
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
                  uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s);
+// writes 1 to *d_out when v_pk_minimum3_f16 / v_pk_maximum3_f16 order f16 denormal bit patterns like integers in this build
+// (what the FAST score kernels rely on: arc_score.hpp); checked once per context by mslam_hip_create
+void launch_denorm_selfcheck(uint32_t* d_out, hipStream_t s);
 struct QuadArgs
 {
     const uint32_t* cell_cnt; // [B][n_cells]
@@ -214,6 +217,10 @@ struct DescArgs
     // selection kernel, and cos / sin of the angle follow computeOrbDescriptors (float degree -> radian product,
     // include/mslam_sincos.h in place of the host libm) instead of the in-tree util::cos / util::sin
     const float* sel_resp = nullptr; // [B][L][cand_cap], parallel to sel
+    // the synchronous single-frame call: the page-locked, device-mapped result block of the context (count, flags, then xy /
+    // descriptors / octave / angle / response at capacity strides).  When set, k_describe writes every result there as well —
+    // its stores are the transfer, no packing kernel follows (5 us of the call)
+    uint8_t* h_mirror = nullptr;
     int cv_mode = 0;
 };
 void launch_describe(const Geometry& g, const DescArgs& a, int frame0, int n_frames, hipStream_t s);
@@ -293,5 +300,8 @@ struct RatioArgs
     int32_t* n_out;     // [n_pairs]
 };
 void launch_ratio_compact(const RatioArgs& a, int n_pairs, hipStream_t s);
+// ONE pair, matrix-core kernel with sliced train tiles, then merge + ratio test + compaction in one launch (mslam_hip_match);
+// false: the arguments do not fit this form and nothing was launched
+bool launch_match_ratio_single(const MatchArgs& a, const RatioArgs& r, hipStream_t s);
 
 } // namespace mslam

@@ -74,6 +74,11 @@ struct mslam_hip_ctx
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
     hipGraphExec_t detect_graph[2] = {nullptr, nullptr}; // mslam_hip_detect's kernel + copy sequence, per output set
     bool use_graph = true;
+    bool mirror_results = false; // set by mslam_hip_detect around its enqueue: k_describe writes the results into h_out as well (no packing kernel)
+    // mslam_hip_match's sequence (descriptor upload + matcher + merge + ratio test) as a graph: sizes come from a mapped word pair,
+    // the launch shapes from the staging capacities, so one graph serves every call until the capacities or the matcher change
+    hipGraphExec_t match_graph = nullptr;
+    int match_graph_from_cap = 0, match_graph_to_cap = 0, match_graph_kind = -1, match_graph_kernel = 0;
     uint8_t* d_h_out = nullptr;     // the device address of h_out (page-locked, mapped)
     uint8_t* h_out = nullptr;       // pinned staging of mslam_hip_detect's results: [count, flags | xy | desc | octave | angle | response] for K keypoints
     double ratio_cached = -1.0;
@@ -109,6 +114,7 @@ struct mslam_hip_ctx
     int n_last = 0;         // frames in the last detect batch
     unsigned long long detect_seq = 0; // counts detect batches; points_seq = the batch the back-projected points belong to
     unsigned long long points_seq = ~0ull;
+    unsigned long long match_seq = ~0ull; // the detect batch mslam_hip_match_batch_dev last matched (mslam_hip_pack_batch_dev packs no stale pairs)
     bool have_prev = false; // slot 0 holds a real predecessor of the current batch
 
     // matcher

@@ -191,6 +191,11 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
         a.count[frame] = min(total, a.max_kp);
         if(total > a.max_kp)
             atomicOr(a.flags, kFlagKpOverflow);
+        if(a.h_mirror) // (one frame per launch; the flags of the earlier kernels of the call are final by now)
+        {
+            reinterpret_cast<int32_t*>(a.h_mirror)[0] = min(total, a.max_kp);
+            reinterpret_cast<uint32_t*>(a.h_mirror)[1] = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (total > a.max_kp ? kFlagKpOverflow : 0u);
+        }
     }
     const int n_kp = min(total, a.max_kp);
 
@@ -575,6 +580,21 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
             a.octave[o] = my_level;
             a.angle[o] = my_angle;
             a.response[o] = my_resp;
+        }
+        if(a.h_mirror) // wave-uniform: the same records into the mapped host block (layout of mslam_hip_detect's staging block)
+        {
+            const size_t K = (size_t)a.max_kp;
+            uint8_t* h = a.h_mirror + 16;
+            if(lane < 4 * n_here)
+                reinterpret_cast<uint2*>(h + K * 8 + (size_t)(base + (lane >> 2) * kStr) * 32)[lane & 3] = make_uint2(desc_lo, desc_hi);
+            if(lane < n_here)
+            {
+                const size_t o = (size_t)(base + lane * kStr);
+                reinterpret_cast<float2*>(h)[o] = make_float2(my_ox, my_oy);
+                reinterpret_cast<int32_t*>(h + K * 40)[o] = my_level;
+                reinterpret_cast<float*>(h + K * 44)[o] = my_angle;
+                reinterpret_cast<float*>(h + K * 48)[o] = my_resp;
+            }
         }
     }
 }

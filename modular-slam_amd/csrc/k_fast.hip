@@ -392,6 +392,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         cell_cnt[frame * g.n_cells + cell_id] = total;
 }
 
+// One-off self-check at context creation (api.hip): arc_score2_raw and the FAST kernels of both detector modes order the f16
+// DENORMAL bit patterns 0x0000 .. 0x00FF (raw pixels) with v_pk_minimum3_f16 / v_pk_maximum3_f16, which holds only while the
+// kernels run with f16 denormals preserved (.amdhsa_float_denorm_mode_16_64 3, the compiler's default).  A build flag or a
+// function attribute that flushes them would collapse every score without a compile-time signal: this kernel — compiled in
+// this translation unit, with the same flags — evaluates the two instructions on such patterns, and creation fails loudly if
+// the result is not the integer min / max.  out[0] = 1 when every check holds.
+__global__ void k_denorm_selfcheck(uint32_t* out)
+{
+    const uint32_t t = threadIdx.x; // 64 lanes: patterns (t, 255 - t) in the two halves
+    const uint32_t a = t | ((255u - t) << 16), b = ((t * 7u + 3u) & 255u) | (((t * 13u + 1u) & 255u) << 16), c = 1u | (254u << 16);
+    const uint32_t mx = pk_max3(a, b, c), mn = pk_min3(a, b, c);
+    auto lo = [](uint32_t x) { return x & 0xFFFFu; };
+    auto hi = [](uint32_t x) { return x >> 16; };
+    const bool ok = lo(mx) == max(max(lo(a), lo(b)), lo(c)) && hi(mx) == max(max(hi(a), hi(b)), hi(c)) &&
+                    lo(mn) == min(min(lo(a), lo(b)), lo(c)) && hi(mn) == min(min(hi(a), hi(b)), hi(c));
+    const unsigned long long all = __ballot(ok);
+    if(t == 0)
+        out[0] = all == ~0ull ? 1u : 0u;
+}
+
+void launch_denorm_selfcheck(uint32_t* d_out, hipStream_t s) { hipLaunchKernelGGL(k_denorm_selfcheck, dim3(1), dim3(64), 0, s, d_out); }
+
 void launch_fast(const uint8_t* d_pyr, const Geometry& g, const CellDesc* d_cells, uint32_t* d_cell_cnt,
                  uint32_t* d_cell_kp, int ini_thr, int min_thr, int frame0, int n_frames, hipStream_t s)
 {

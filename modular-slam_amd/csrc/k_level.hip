@@ -21,7 +21,9 @@
 // The arithmetic is the one of k_gray4 / k_resize_col / k_blur2, whose stand-alone forms stay as the generic fallbacks
 // (widths that are not a multiple of 4 at level 0, scale factors beyond the 12-byte window, batches beyond 32-bit offsets).
 #include "common.hpp"
+#include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace mslam
 {
@@ -157,11 +159,21 @@ struct Bgr3
     uint32_t a, b, c;
 };
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
 // ---- level 0: gray + blur --------------------------------------------------------------------------------------------
 // TILED: the blurred plane is written in kTileW x kTileH pixel tiles (common.hpp: tiled_off; k_describe's patches then
 // touch fewer lines).  A lane's dword keeps its place inside the tile row (its vector offset); the row's offset inside the
 // plane — tiled_off(pitch, 0, y) — is wave-uniform and rides in the store's scalar offset.
-template <bool TILED>
+// DEEP = N > 0: the launch is a handful of waves (the synchronous single-frame call) and lasts as long as ONE wave's walk, so
+// all N = R + 6 rows of the block are requested before the first is used (N x 3 registers) instead of two rows ahead: one
+// memory round trip per block instead of one per two rows.
+template <bool TILED, int DEEP>
 __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -206,17 +218,11 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
 #pragma unroll
     for(int j = 0; j < 4; ++j)
         st.hprev[j] = 0;
-    Bgr3 ring[3];
-    ring[0] = load(0);
-    ring[1] = load(1);
-
     // one row: i = i0 + PH, PH = i % 6 (static); RAW: the row belongs to the block (rows 3 .. R+2), BLUR: i >= 6
-    auto row = [&](auto ph, auto emit, auto sraw, int i, bool raw) {
+    auto compute = [&](auto ph, auto emit, auto sraw, int i, bool raw, const Bgr3& w) {
         constexpr int PH = decltype(ph)::value;
         constexpr bool EMIT = decltype(emit)::value;
         constexpr bool SRAW = decltype(sraw)::value; // false for block rows 0 .. 2: no raw store is emitted at all
-        ring[(PH + 2) % 3] = load(min(i + 2, R + 5));
-        const Bgr3 w = ring[PH % 3];
         const uint32_t g = lv_gray4(w.a, w.b, w.c);
         if(SRAW) // rows 3 .. R+2 need no reflection; a halo row is stored against an empty buffer
             __builtin_amdgcn_raw_buffer_store_b32(g, __builtin_amdgcn_make_buffer_rsrc(a.pyr, 0, __builtin_amdgcn_readfirstlane(raw ? (int)n_rec : 0), 0x00020000),
@@ -227,6 +233,29 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
                                                   (int)(TILED ? tiled_off((unsigned)a.pitch, 0, y0 - 6 + i) : (unsigned)((y0 - 6 + i) * a.pitch)), 0);
     };
     using std::integral_constant;
+    if constexpr(DEEP > 0)
+    {
+        // (host: R + 6 == DEEP) every row of the block in flight at once, then the rows in order
+        Bgr3 all[DEEP];
+#pragma unroll
+        for(int i = 0; i < DEEP; ++i)
+            all[i] = load(i);
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler would otherwise sink every load to its use)
+        static_for([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr bool RAWROW = I >= 3 && I <= DEEP - 4; // rows 3 .. R + 2
+            compute(integral_constant<int, I % 6>{}, integral_constant<bool, (I >= 6)>{}, integral_constant<bool, RAWROW>{}, I, RAWROW, all[I]);
+        }, std::make_integer_sequence<int, DEEP>{});
+        return;
+    }
+    Bgr3 ring[3];
+    ring[0] = load(0);
+    ring[1] = load(1);
+    auto row = [&](auto ph, auto emit, auto sraw, int i, bool raw) {
+        constexpr int PH = decltype(ph)::value;
+        ring[(PH + 2) % 3] = load(min(i + 2, R + 5));
+        compute(ph, emit, sraw, i, raw, ring[PH % 3]);
+    };
 #define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
     // rows 0 .. 5: fill the ring (rows 3, 4, 5 are the block's first rows)
     MSLAM_ROW(0, false, false, 0, false);
@@ -270,7 +299,9 @@ struct HRow
 // NEED: bit k set = pixel k of a quad may take its (S[x], S[x+1]) pair from window dwords (1,2) instead of (0,1) — a
 // compile-time superset of the level's mask (at scale 1.2 only the fourth pixel ever does), so that the other pixels carry
 // no per-lane selects
-template <bool EXACT, int NEED, bool TILED>
+// DEEP = N > 0: as in k_gray_blur — both source-row windows of all N = R + 6 rows of the block are requested up front (the
+// single-frame launches, whose duration is one wave's walk: 6 N registers)
+template <bool EXACT, int NEED, bool TILED, int DEEP>
 __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -355,34 +386,10 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     int rowA = -1, rowB = -1; // wave-uniform: which source rows hA / hB hold
     // both source rows of every destination row are requested two rows ahead, unconditionally (static 3-deep ring: the
     // compiler can count its vmcnt waits); whether a row is interpolated again or taken over from hB is decided at use
-    Raw3 RA[3], RB[3];
-    // the source rows of block rows i and i + 1 are carried from the iterations that requested them (one table lookup per row)
-    int c0_y0, c0_y1, c1_y0, c1_y1;
-    rows_of(0, c0_y0, c0_y1);
-    rows_of(1, c1_y0, c1_y1);
-    RA[0] = load(c0_y0);
-    RB[0] = load(c0_y1);
-    RA[1] = load(c1_y0);
-    RB[1] = load(c1_y1);
-
-    auto row = [&](auto ph, auto emit, auto sraw, int i, bool raw) {
+    auto compute = [&](auto ph, auto emit, auto sraw, int i, bool raw, int sy0, int sy1, const Raw3& wA, const Raw3& wB) {
         constexpr int PH = decltype(ph)::value;
         constexpr bool EMIT = decltype(emit)::value;
         constexpr bool SRAW = decltype(sraw)::value; // false for block rows 0 .. 2: no raw store is emitted at all
-        const int sy0 = c0_y0, sy1 = c0_y1;
-        {
-            int ny0, ny1;
-            rows_of(min(i + 2, R + 5), ny0, ny1);
-            // hA of row i + 2 is taken over from hB when its upper source row is the lower one of row i + 1 (the common step at
-            // scale factors below 2): that row's window is then never looked at — the load still issues (the compiler counts
-            // its vmcnt waits statically) but against an empty buffer, which returns zeros without touching the cache
-            // (0.72 -> 0.68 ms per 1000 frames; an empty-buffer load takes longer to return than a cache hit, so the handful-of-
-            // frames launches, which run at the latency of one wave's walk, keep the real load: always_load)
-            RA[(PH + 2) % 3] = load_if(ny0, ny0 != c1_y1 || a.always_load);
-            RB[(PH + 2) % 3] = load(ny1);
-            c0_y0 = c1_y0, c0_y1 = c1_y1;
-            c1_y0 = ny0, c1_y1 = ny1;
-        }
         // bring (hA, hB) to (sy0, sy1).  All conditions are wave-uniform; the empty asm statements keep the compiler from
         // turning the branches into speculated work + selects.
         const bool reuse = sy1 == rowB && (sy0 == rowA || sy0 == rowB);
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
             else
             {
                 asm volatile("");
-                hA = hinterp(RA[PH % 3]);
+                hA = hinterp(wA);
             }
             rowA = sy0;
             if(sy1 == sy0)
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
             else
             {
                 asm volatile("");
-                hB = hinterp(RB[PH % 3]);
+                hB = hinterp(wB);
             }
             rowB = sy1;
         }
@@ -457,6 +464,56 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
                                                   (int)(TILED ? tiled_off((unsigned)a.dpitch, 0, y0 - 6 + i) : (unsigned)((y0 - 6 + i) * a.dpitch)), 0);
     };
     using std::integral_constant;
+    if constexpr(DEEP > 0)
+    {
+        // (host: R + 6 == DEEP) both windows of every row of the block in flight at once, then the rows in order
+        Raw3 allA[DEEP], allB[DEEP];
+#pragma unroll
+        for(int i = 0; i < DEEP; ++i)
+        {
+            int y0i, y1i;
+            rows_of(i, y0i, y1i);
+            allA[i] = load(y0i);
+            allB[i] = load(y1i);
+        }
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler would otherwise sink every load to its use)
+        static_for([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr bool RAWROW = I >= 3 && I <= DEEP - 4; // rows 3 .. R + 2
+            int sy0, sy1;
+            rows_of(I, sy0, sy1);
+            compute(integral_constant<int, I % 6>{}, integral_constant<bool, (I >= 6)>{}, integral_constant<bool, RAWROW>{}, I, RAWROW, sy0, sy1,
+                    allA[I], allB[I]);
+        }, std::make_integer_sequence<int, DEEP>{});
+        return;
+    }
+    Raw3 RA[3], RB[3];
+    // the source rows of block rows i and i + 1 are carried from the iterations that requested them (one table lookup per row)
+    int c0_y0, c0_y1, c1_y0, c1_y1;
+    rows_of(0, c0_y0, c0_y1);
+    rows_of(1, c1_y0, c1_y1);
+    RA[0] = load(c0_y0);
+    RB[0] = load(c0_y1);
+    RA[1] = load(c1_y0);
+    RB[1] = load(c1_y1);
+    auto row = [&](auto ph, auto emit, auto sraw, int i, bool raw) {
+        constexpr int PH = decltype(ph)::value;
+        const int sy0 = c0_y0, sy1 = c0_y1;
+        {
+            int ny0, ny1;
+            rows_of(min(i + 2, R + 5), ny0, ny1);
+            // hA of row i + 2 is taken over from hB when its upper source row is the lower one of row i + 1 (the common step at
+            // scale factors below 2): that row's window is then never looked at — the load still issues (the compiler counts
+            // its vmcnt waits statically) but against an empty buffer, which returns zeros without touching the cache
+            // (0.72 -> 0.68 ms per 1000 frames; an empty-buffer load takes longer to return than a cache hit, so the handful-of-
+            // frames launches, which run at the latency of one wave's walk, keep the real load: always_load)
+            RA[(PH + 2) % 3] = load_if(ny0, ny0 != c1_y1 || a.always_load);
+            RB[(PH + 2) % 3] = load(ny1);
+            c0_y0 = c1_y0, c0_y1 = c1_y1;
+            c1_y0 = ny0, c1_y1 = ny1;
+        }
+        compute(ph, emit, sraw, i, raw, sy0, sy1, RA[PH % 3], RB[PH % 3]);
+    };
 #define MSLAM_ROW(PH, EMIT, SRAW, I, RAW) row(integral_constant<int, PH>{}, integral_constant<bool, EMIT>{}, integral_constant<bool, SRAW>{}, I, RAW)
     MSLAM_ROW(0, false, false, 0, false);
     MSLAM_ROW(1, false, false, 1, false);
@@ -487,8 +544,13 @@ void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s)
     b.waves_per_xcd = ((n_waves + 31) / 32) * 4; // whole workgroups per XCD
     dim3 grid(8 * (b.waves_per_xcd / 4), (a.dh + R - 1) / R);
     const int need = (a.need_mask & ~8) == 0 ? (a.need_mask ? 8 : 0) : (a.need_mask & ~12) == 0 ? 12 : 15;
-#define MSLAM_RB(E, N) do { if(a.blur_tiled) hipLaunchKernelGGL((k_resize_blur<E, N, true>), grid, dim3(256), 0, s, b); \
-                           else hipLaunchKernelGGL((k_resize_blur<E, N, false>), grid, dim3(256), 0, s, b); } while(0)
+    // a handful of frames (always_load) with 2- or 8-row blocks: the deep-prefetch instances (MSLAM_HIP_LEVEL_DEEP=0: off)
+    static const bool deep_env = [] { const char* e = getenv("MSLAM_HIP_LEVEL_DEEP"); return !e || atoi(e) != 0; }();
+    const int deep = (a.always_load && deep_env && a.k6 <= 1) ? R + 6 : 0;
+#define MSLAM_RB3(E, N, T) do { if(deep == 8) hipLaunchKernelGGL((k_resize_blur<E, N, T, 8>), grid, dim3(256), 0, s, b); \
+                               else if(deep == 14) hipLaunchKernelGGL((k_resize_blur<E, N, T, 14>), grid, dim3(256), 0, s, b); \
+                               else hipLaunchKernelGGL((k_resize_blur<E, N, T, 0>), grid, dim3(256), 0, s, b); } while(0)
+#define MSLAM_RB(E, N) do { if(a.blur_tiled) MSLAM_RB3(E, N, true); else MSLAM_RB3(E, N, false); } while(0)
     if(a.exact)
     {
         if(need == 0) MSLAM_RB(true, 0); else if(need == 8) MSLAM_RB(true, 8); else if(need == 12) MSLAM_RB(true, 12); else MSLAM_RB(true, 15);
@@ -497,6 +559,7 @@ void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s)
     {
         if(need == 0) MSLAM_RB(false, 0); else if(need == 8) MSLAM_RB(false, 8); else if(need == 12) MSLAM_RB(false, 12); else MSLAM_RB(false, 15);
     }
+#undef MSLAM_RB3
 #undef MSLAM_RB
 }
 
@@ -507,10 +570,16 @@ void launch_gray_blur(const GrayBlurArgs& a, hipStream_t s)
     GrayBlurArgs b = a;
     b.waves_per_xcd = ((n_waves + 31) / 32) * 4; // whole workgroups per XCD
     dim3 grid(8 * (b.waves_per_xcd / 4), (a.H + R - 1) / R);
+    static const bool deep_env = [] { const char* e = getenv("MSLAM_HIP_LEVEL_DEEP"); return !e || atoi(e) != 0; }();
+    const int deep = (a.n_frames < 8 && deep_env && a.k6 <= 1) ? R + 6 : 0;
+#define MSLAM_GB(T) do { if(deep == 8) hipLaunchKernelGGL((k_gray_blur<T, 8>), grid, dim3(256), 0, s, b); \
+                        else if(deep == 14) hipLaunchKernelGGL((k_gray_blur<T, 14>), grid, dim3(256), 0, s, b); \
+                        else hipLaunchKernelGGL((k_gray_blur<T, 0>), grid, dim3(256), 0, s, b); } while(0)
     if(a.blur_tiled)
-        hipLaunchKernelGGL(k_gray_blur<true>, grid, dim3(256), 0, s, b);
+        MSLAM_GB(true);
     else
-        hipLaunchKernelGGL(k_gray_blur<false>, grid, dim3(256), 0, s, b);
+        MSLAM_GB(false);
+#undef MSLAM_GB
 }
 
 } // namespace mslam

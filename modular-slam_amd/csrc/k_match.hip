@@ -206,6 +206,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int t_begin = a.n_slices > 1 ? (int)((long long)n_tiles * blockIdx.y / a.n_slices) : 0;
     const int t_end = a.n_slices > 1 ? (int)((long long)n_tiles * (blockIdx.y + 1) / a.n_slices) : n_tiles;
 
+    if(a.n_slices > 1 && n_tiles != 0 && t_begin >= t_end)
+    {
+        // a slice without tiles (fewer train tiles than slices: the captured single-pair launch always has all of them): its
+        // top-2 keys are "no neighbour" (0: below every real key), which k_match_merge's maxima ignore
+#pragma unroll
+        for(int u = 0; u < QT; ++u)
+        {
+            const int q = q0 + (wave * QT + u) * 32 + r;
+            if(h == 0 && q < n_to)
+            {
+                uint32_t* part = a.partial + ((size_t)pair * a.n_slices + blockIdx.y) * 2 * a.cap;
+                part[q] = 0u;
+                part[a.cap + q] = 0u;
+            }
+        }
+        return;
+    }
     if(n_tiles == 0)
     {
         // no train rows at all: every query gets "no neighbour"
@@ -551,6 +568,83 @@ __global__ __launch_bounds__(256) void k_ratio_compact(RatioArgs a)
     }
     if(tid == 0)
         a.n_out[pair] = (int32_t)base;
+}
+
+// The single synchronous call (mslam_hip_match): merge of the slices' top-2 keys (k_match_merge), ratio test and ordered
+// compaction (k_ratio_compact) in ONE launch of one 1024-thread workgroup — two launches of a few microseconds each were a
+// quarter of the call's GPU time.  Pair 0 only; the raw top-2 arrays are not written (mslam_hip_match does not return them).
+__global__ __launch_bounds__(1024) void k_merge_ratio(MatchArgs a, RatioArgs r)
+{
+    __shared__ uint32_t wcnt[16];
+    const int n_from = min(a.from_cnt ? a.from_cnt[0] : a.n_from_fixed, MM_MAX_TRAIN);
+    const int n_to = min(a.to_cnt ? a.to_cnt[0] : a.n_to_fixed, a.cap);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = (n_from + 31) >> 5;
+    const int last = 32 * n_tiles - 1;
+    uint32_t base = 0;
+    if(n_from >= 2) // fewer than two train rows: the reference indexes match[1] out of bounds (orb_feature.cpp:101)
+    {
+        for(int q0 = 0; q0 < n_to; q0 += 1024)
+        {
+            const int q = q0 + tid;
+            bool ok = false;
+            int fi = -1;
+            if(q < n_to)
+            {
+                uint32_t b0 = 0u, b1 = 0u;
+                for(int s = 0; s < a.n_slices; ++s)
+                {
+                    const uint32_t* part = a.partial + (size_t)s * 2 * a.cap;
+                    const uint32_t k0 = part[q], k1 = part[a.cap + q]; // k0 >= k1
+                    b1 = max(min(b0, k0), max(b1, k1));
+                    b0 = max(b0, k0);
+                }
+                const uint32_t k0 = (uint32_t)__uint_as_float(b0), k1 = (uint32_t)__uint_as_float(b1); // exact integers
+                // key >> 15 = 257 - hamming; a key without a neighbour decodes to distance INT_MAX, which fails the test
+                fi = (k0 >> 15) ? last - (int)(k0 & 32767u) : -1;
+                const int d0 = (k0 >> 15) ? (int)(257u - (k0 >> 15)) : INT_MAX, d1 = (k1 >> 15) ? (int)(257u - (k1 >> 15)) : INT_MAX;
+                ok = d1 <= 256 && d0 < r.thr[d1];
+            }
+            const unsigned long long b = __ballot(ok);
+            if(lane == 0)
+                wcnt[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+#pragma unroll
+            for(int w = 0; w < 16; ++w)
+            {
+                const uint32_t x = wcnt[w];
+                pre += w < wave ? x : 0u;
+                tot += x;
+            }
+            if(ok)
+            {
+                const uint32_t pos = base + pre + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                r.from_idx[pos] = fi;
+                r.to_idx[pos] = q;
+            }
+            base += tot;
+            __syncthreads();
+        }
+    }
+    if(tid == 0)
+        r.n_out[0] = (int32_t)base;
+}
+
+// matcher + merge + ratio test of ONE pair with sliced train tiles, for mslam_hip_match; returns false when the arguments
+// do not fit this form (the caller then takes launch_match_knn2 + launch_ratio_compact)
+bool launch_match_ratio_single(const MatchArgs& a, const RatioArgs& r, hipStream_t s)
+{
+    const int max_train = a.from_cnt ? a.cap_from : a.n_from_fixed;
+    if(max_train > MM_MAX_TRAIN || a.popcount_only || a.n_slices <= 1 || !a.partial)
+        return false;
+    MatchArgs m = a;
+    m.n_pairs = 1;
+    m.wg_per_pair = (m.cap + 128 * 2 - 1) / (128 * 2);
+    const unsigned grid = 8u * (unsigned)m.wg_per_pair;
+    hipLaunchKernelGGL((k_match_knn2_fp4<2, false>), dim3(grid, m.n_slices), dim3(256), 0, s, m);
+    hipLaunchKernelGGL(k_merge_ratio, dim3(1), dim3(1024), 0, s, m, r);
+    return true;
 }
 
 void launch_ratio_compact(const RatioArgs& a, int n_pairs, hipStream_t s)

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_pack_plan(const int32_t* __restrict__ 
     for(int base = 0; base < n_frames; base += 1024)
     {
         const int t = base + tid;
-        uint32_t v[2] = {t < n_frames ? (uint32_t)min(max(count[t], 0), cap) : 0u, t < n_frames ? (uint32_t)min(max(mcount[t], 0), cap) : 0u};
+        uint32_t v[2] = {t < n_frames ? (uint32_t)min(max(count[t], 0), cap) : 0u, (t < n_frames && mcount) ? (uint32_t)min(max(mcount[t], 0), cap) : 0u}; // (mcount == nullptr: no matches of this batch)
         uint32_t inc[2];
 #pragma unroll
         for(int k = 0; k < 2; ++k)
@@ -255,7 +255,10 @@ int mslam_hip_pack_batch_dev(mslam_hip_ctx* c, void* out, size_t capacity_bytes,
     if(rc)
         return rc;
     const size_t K = (size_t)c->p.max_keypoints;
-    hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(1024), 0, c->stream, c->d_count + 1, c->d_mcount, c->n_last, c->p.max_keypoints,
+    // the matcher's outputs belong to the batch match_batch_dev last ran on: when that is not this detect batch (match_seq), the
+    // slot still holds an older batch's pairs, and the batch is packed with zero matches instead of those
+    const int32_t* mcount = c->match_seq == c->detect_seq ? c->d_mcount : nullptr;
+    hipLaunchKernelGGL(k_pack_plan, dim3(1), dim3(1024), 0, c->stream, c->d_count + 1, mcount, c->n_last, c->p.max_keypoints,
                        with_points ? 1 : 0, (unsigned long long)capacity_bytes, static_cast<uint8_t*>(out), c->d_flags);
     hipLaunchKernelGGL(k_pack_copy, dim3(c->n_last, 4), dim3(256), 0, c->stream, c->d_xy + K * 2, c->d_desc + K * 32, c->d_octave + K,
                        c->d_angle + K, c->d_response + K, c->d_xyz, c->d_valid, c->d_mfrom, c->d_mto, c->p.max_keypoints,

@@ -153,6 +153,11 @@ def refine(R, t, obj, img, cam, mask, iters=50):
     return R, t, c
 
 
+# modelPoints of RANSACUpdateNumIters as cv::solvePnPRansac sets it for the reference's call (default flags, more than 4
+# points: 5, calib3d/src/solvepnp.cpp) — the library's own minimal sample is 3 + 1 points, its stopping rule is the call site's
+MODEL_POINTS = 5
+
+
 def update_num_iters(p, ep, model_points, max_iters):
     """OpenCV's RANSACUpdateNumIters (calib3d/src/ptsetreg.cpp): samples needed to have drawn an all-inlier one with
     probability p when a share ep of the points are outliers; p outside (0, 1): no early exit"""
@@ -184,7 +189,7 @@ def pnp_ransac(obj, img, cam, iterations=100, thr=5.0, seed=0, guess=None, confi
         counts.append(-1 if hy is None else int(inliers_of(hy[0], hy[1], obj, img, cam, thr).sum()))
         if counts[h] > max(bc, 3):
             bc, best = counts[h], h
-            niters = update_num_iters(confidence, (n - bc) / n, 4, niters)
+            niters = update_num_iters(confidence, (n - bc) / n, MODEL_POINTS, niters)
         h += 1
     if best < 0:
         return None

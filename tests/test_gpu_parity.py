@@ -385,6 +385,17 @@ def test_packed_batch_results(pkg, synth_frames):
     with pytest.raises(pkg.MslamHipError):
         pkg.unpack_batch(h)
     assert (h[1024:] == 0xAB).all()
+    # a second detect batch that the matcher has not run on is packed with ZERO matches, not with the first batch's pairs
+    c.detect_batch_dev(dev.data_ptr(), B)
+    c.pack_batch_dev(buf.data_ptr(), cap, False)
+    c.sync()
+    p2 = pkg.unpack_batch(buf.cpu().numpy())
+    assert np.array_equal(np.diff(p2["kp_offset"]), cnt) and not np.diff(p2["match_offset"]).any() and len(p2["match_from"]) == 0
+    c.match_batch_dev(0.7, True)
+    c.pack_batch_dev(buf.data_ptr(), cap, False)
+    c.sync()
+    p3 = pkg.unpack_batch(buf.cpu().numpy())
+    assert np.diff(p3["match_offset"]).min() > 100     # chained: frame 0 has the previous batch's last frame as predecessor
     c.close()
 
 

@@ -50,11 +50,14 @@ def test_oracle_recovers_ground_truth():
 
 def test_oracle_confidence_bound_ends_clean_scenes_early():
     """cv_ransac_pnp.cpp:57 passes confidence 0.99: RANSACUpdateNumIters on every new best hypothesis.  A clean scene needs a
-    handful of hypotheses, a 60 %-outlier scene (w^4 = 2.6 %: 178 samples for 0.99) runs all 100; without a confidence the
-    loop never ends early; and the winner is the first maximum of the hypotheses looked at."""
-    assert po.update_num_iters(0.99, 0.0, 4, 100) == 0 and po.update_num_iters(0.99, 0.6, 4, 100) == 100
-    assert po.update_num_iters(0.99, 0.1, 4, 100) == 4 and po.update_num_iters(0.99, 0.3, 4, 100) == 17
-    assert po.update_num_iters(1.0, 0.1, 4, 100) == 100 and po.update_num_iters(0.0, 0.1, 4, 100) == 100
+    handful of hypotheses, a 60 %-outlier scene (w^5 = 1 %: 447 samples for 0.99) runs all 100; without a confidence the
+    loop never ends early; and the winner is the first maximum of the hypotheses looked at.  The model-point count of the
+    formula is the call site's (5: solvePnPRansac with default flags), pinned here: 25 hypotheses at 30 % outliers, not 17."""
+    assert po.MODEL_POINTS == 5
+    assert po.update_num_iters(0.99, 0.0, 5, 100) == 0 and po.update_num_iters(0.99, 0.6, 5, 100) == 100
+    assert po.update_num_iters(0.99, 0.1, 5, 100) == 5 and po.update_num_iters(0.99, 0.3, 5, 100) == 25
+    assert po.update_num_iters(0.99, 0.3, 4, 100) == 17
+    assert po.update_num_iters(1.0, 0.1, 5, 100) == 100 and po.update_num_iters(0.0, 0.1, 5, 100) == 100
     obj, img, R, t, good = scene(21, outliers=0.0)
     clean = po.pnp_ransac(obj, img, CAM, seed=2)
     assert clean["looked_at"] <= 8 and rot_err(clean["R"], R) < 0.1

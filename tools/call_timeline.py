@@ -8,11 +8,13 @@ calls, cur = [], []
 for r in rows:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mslam::", "")
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    if ("k_gray" in n or "k_carry_prev" in n) and cur and any("k_pack_results" in x[0] for x in cur):
+    # a call starts with the carry kernel (or the gray kernel when there is none) once the previous call has described its frame
+    # (k_pack_results followed k_describe until round 5: k_describe now writes the mapped result block itself)
+    if ("k_gray" in n or "k_carry_prev" in n) and cur and any("k_describe" in x[0] for x in cur):
         calls.append(cur)
         cur = []
     cur.append((n, s, e))
-calls = [c for c in calls[5:] if any("k_pack_results" in x[0] for x in c)]
+calls = [c for c in calls[5:] if any("k_describe" in x[0] for x in c)]
 if not calls:
     raise SystemExit("no complete call in the trace")
 sig = collections.Counter(tuple(x[0] for x in c) for c in calls).most_common(1)[0][0]
