@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MSLAM_HIP_ABI_VERSION 4
+#define MSLAM_HIP_ABI_VERSION 5
 
 enum
 {
@@ -62,13 +62,23 @@ enum
     /* DistributedOrbOpenCvDetector (distributed_cv_feature.cpp:1181-1222): 64-px FAST cells + quadtree, util::cos/sin */
     MSLAM_HIP_DETECTOR_DISTRIBUTED = 0,
     /* OrbOpenCvDetector (orb_feature.cpp:25,33-65): toGrayScale + cv::ORB::create(n)->detectAndCompute — INTER_LINEAR_EXACT
-     * pyramid, whole-level FAST, retainBest(2n) / Harris response / retainBest(n) per level, libm-style cos/sin.  Two
-     * documented deviations: keypoints of a level come in FAST raster order (the reference's order is what
-     * std::nth_element leaves behind: implementation-defined; the SET is the same), and cos/sin come from
-     * include/mslam_sincos.h (correctly rounded in practice) instead of the host libm's cosf/sinf.  n_levels,
-     * scale_factor, ini_fast_thr keep their meaning; min_fast_thr / min_node_area are unused. */
+     * pyramid, whole-level FAST, retainBest(2n) / Harris response / retainBest(n) per level, libm-style cos/sin.
+     * Keypoint ORDER inside a level: what KeyPointsFilter::retainBest's std::nth_element + std::partition leave behind —
+     * defined by the C++ library, not by the standard.  The reference is a GCC build, so the default reproduces libstdc++'s
+     * introselect / partition step by step (mslam_hip_set_cv_keypoint_order); the raster order of FAST is the alternative.
+     * One documented deviation: cos/sin come from include/mslam_sincos.h (correctly rounded in practice) instead of the host
+     * libm's cosf/sinf.  n_levels, scale_factor, ini_fast_thr keep their meaning; min_fast_thr / min_node_area are unused. */
     MSLAM_HIP_DETECTOR_CV_ORB = 1
 };
+/* CV_ORB detector: where the two retainBest calls of a level leave their survivors (the kept SET is the same either way).
+ * LIBSTDCXX (default) = the order of a GCC build of the reference, hence its keypoint ids and DescriptorMatch indices;
+ * RASTER = FAST's (y, x) order — a little faster (the selection is then a threshold and a compaction). */
+enum
+{
+    MSLAM_HIP_CV_ORDER_LIBSTDCXX = 0,
+    MSLAM_HIP_CV_ORDER_RASTER = 1
+};
+int mslam_hip_set_cv_keypoint_order(mslam_hip_ctx* ctx, int order);
 
 void mslam_hip_default_params(mslam_hip_params* p);
 int mslam_hip_abi_version(void);

@@ -28,6 +28,7 @@ DBG_PYRAMID, DBG_BLURRED, DBG_CANDIDATES, DBG_SELECTED = range(4)
 MATCHER_AUTO, MATCHER_POPCOUNT = 0, 1
 DETECTOR_DISTRIBUTED, DETECTOR_CV_ORB = 0, 1
 BOW_ASSIGN_TREE, BOW_ASSIGN_FLAT = 0, 1
+CV_ORDER_LIBSTDCXX, CV_ORDER_RASTER = 0, 1
 
 # every symbol include/mslam_hip.h declares (tests/test_cabi.py checks the .so exports them all)
 ABI_SYMBOLS = [
@@ -44,6 +45,7 @@ ABI_SYMBOLS = [
     "mslam_hip_join_matcher", "mslam_hip_bow_db_remove", "mslam_hip_bow_set_assignment",
     "mslam_hip_bow_db_reserve", "mslam_hip_bow_db_size", "mslam_hip_qlz_decompress",
     "mslam_hip_pnp_ransac", "mslam_hip_pnp_batch_dev", "mslam_hip_get_pnp_view", "mslam_hip_pnp_set_confidence", "mslam_hip_pack_batch_dev", "mslam_hip_packed_capacity",
+    "mslam_hip_set_cv_keypoint_order",
 ]
 
 
@@ -238,6 +240,10 @@ class Context:
 
     def get_matcher(self):
         return self.L.mslam_hip_get_matcher(self._h)
+
+    def set_cv_keypoint_order(self, order):
+        """CV_ORDER_LIBSTDCXX (default: the order of a GCC build of the reference) or CV_ORDER_RASTER (FAST's order)."""
+        self._chk(self.L.mslam_hip_set_cv_keypoint_order(self._h, int(order)))
 
     def last_match_kernel(self):
         """'matrix' / 'popcount': the kernel the last matcher launch took (None before the first)"""

@@ -994,6 +994,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             sa.flags = c->d_flags;
             sa.cand_cap = c->p.max_candidates;
             sa.edge = c->p.edge_threshold;
+            sa.std_order = c->cv_order == MSLAM_HIP_CV_ORDER_LIBSTDCXX ? 1 : 0;
             for(int l = 0; l < g.n_levels; ++l)
                 sa.quota[l] = c->cv_quota[l];
             {
@@ -1544,6 +1545,25 @@ int mslam_hip_set_matcher(mslam_hip_ctx* c, int kind)
 }
 
 int mslam_hip_get_matcher(const mslam_hip_ctx* c) { return c ? c->matcher_kind : -1; }
+
+int mslam_hip_set_cv_keypoint_order(mslam_hip_ctx* c, int order)
+{
+    ENTER(c);
+    if(order != MSLAM_HIP_CV_ORDER_LIBSTDCXX && order != MSLAM_HIP_CV_ORDER_RASTER)
+        return fail(c, MSLAM_HIP_E_INVALID, "set_cv_keypoint_order: unknown order");
+    if(order == c->cv_order)
+        return MSLAM_HIP_OK;
+    // the captured single-frame sequences carry the order as a kernel argument: drop them, the next call captures again
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for(auto& e : c->detect_graph)
+        if(e)
+        {
+            (void)hipGraphExecDestroy(e);
+            e = nullptr;
+        }
+    c->cv_order = order;
+    return MSLAM_HIP_OK;
+}
 int mslam_hip_last_match_kernel(const mslam_hip_ctx* c) { return c ? c->last_match_kernel : -1; }
 
 int mslam_hip_match_knn2(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, const uint8_t* to_desc, int n_to,

@@ -253,6 +253,7 @@ struct CvSelectArgs
     int cand_cap;
     int edge;           // edgeThreshold (31)
     int quota[kMaxLevels]; // nfeaturesPerLevel
+    int std_order;         // 1: retainBest leaves its survivors where libstdc++'s nth_element + partition put them (the reference's order), 0: raster order
 };
 void launch_zero_u32(uint32_t* p, int n, hipStream_t s);
 void launch_fast_tiles(const uint8_t* d_pyr, const Geometry& g, int thr, const CvSelectArgs& a, int frame0, int n_frames,

@@ -74,6 +74,7 @@ struct mslam_hip_ctx
     uint32_t* d_orient_w = nullptr; // [2][256] intensity-centroid disc weights
     hipGraphExec_t detect_graph[2] = {nullptr, nullptr}; // mslam_hip_detect's kernel + copy sequence, per output set
     bool use_graph = true;
+    int cv_order = 0; // MSLAM_HIP_CV_ORDER_*: the cv::ORB mode's keypoint order inside a level (mslam_hip_set_cv_keypoint_order)
     bool mirror_results = false; // set by mslam_hip_detect around its enqueue: k_describe writes the results into h_out as well (no packing kernel)
     // mslam_hip_match's sequence (descriptor upload + matcher + merge + ratio test) as a graph: sizes come from a mapped word pair,
     // the launch shapes from the staging capacities, so one graph serves every call until the capacities or the matcher change

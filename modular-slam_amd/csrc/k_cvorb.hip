@@ -435,13 +435,237 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x,
     return __fmul_rn(v, s4);
 }
 
+// ---- KeyPointsFilter::retainBest in the ORDER a GCC build of the reference leaves -------------------------------------------
+// retainBest(keypoints, n) = std::nth_element(begin, begin + n - 1, end, response greater) + std::partition(begin + n, end,
+// response >= keypoints[n - 1].response) + resize (OpenCV features2d/src/keypoint.cpp): the surviving SET is the standard's,
+// their ORDER is what libstdc++'s introselect and partition happen to do — and it is the order of the reference's output
+// (orb_feature.cpp:25,40 -> orb.cpp computeKeyPoints), so of every DescriptorMatch index downstream.  Both library loops are
+// Hoare-style pointer walks, and a Hoare pass is a PARALLEL operation in disguise: the left pointer only ever stops at
+// elements that are "left stoppers" in the ORIGINAL array (response <= pivot), the right pointer at "right stoppers"
+// (response >= pivot), swapped elements are never looked at again before the pointers cross, so pass = swap the k-th left
+// stopper with the k-th right stopper (from the right) while the former lies left of the latter, and the cut is where the
+// left pointer stops next.  Two ordered compactions (ranks by workgroup scans) + one parallel swap per pass; the O(1) pieces
+// (median of three, the <= 3-element insertion sort) and the depth-limit fallback (heap select: adversarial inputs only) run
+// on one thread, literally as in bits/stl_algo.h / stl_heap.h.  The CPU checker restates the same library code sequentially
+// and is pinned against the real <algorithm> of the build image (tests/test_oracle_std_order.py).
+// keys / resp: the n elements (both arrays are permuted together); lsp / rsp: scratch for n ranks; returns the new count.
+template <class IDX>
+__device__ __forceinline__ int retain_best_std(uint32_t* keys, float* resp, int n, int n_points, IDX* lsp, IDX* rsp, uint32_t* wsum,
+                                               int* sh)
+{
+    if(n_points < 0 || n <= n_points)
+        return n;
+    if(n_points == 0)
+        return 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto swap_el = [&](int i, int j) {
+        const uint32_t k = keys[i];
+        keys[i] = keys[j];
+        keys[j] = k;
+        const float r = resp[i];
+        resp[i] = resp[j];
+        resp[j] = r;
+    };
+    // ranks of the elements of [lo, hi) that satisfy fl (-> lsp, ascending) and fr (-> rsp, ascending); totals in nl, nr
+    auto rank2 = [&](int lo, int hi, auto&& fl, auto&& fr, int& nl, int& nr) {
+        uint32_t runl = 0, runr = 0;
+        for(int base = lo; base < hi; base += 256)
+        {
+            const int i = base + tid;
+            const float v = i < hi ? resp[i] : 0.f;
+            const bool bl = i < hi && fl(v), br = i < hi && fr(v);
+            const unsigned long long ml = __ballot(bl), mr = __ballot(br);
+            if(lane == 0)
+                wsum[wave] = (uint32_t)__popcll(ml) | ((uint32_t)__popcll(mr) << 16);
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+            for(int k = 0; k < 4; ++k)
+            {
+                pre += k < wave ? wsum[k] : 0;
+                tot += wsum[k];
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if(bl)
+                lsp[runl + (pre & 0xFFFFu) + (uint32_t)__popcll(ml & below)] = (IDX)i;
+            if(br)
+                rsp[runr + (pre >> 16) + (uint32_t)__popcll(mr & below)] = (IDX)i;
+            runl += tot & 0xFFFFu;
+            runr += tot >> 16;
+            __syncthreads();
+        }
+        nl = (int)runl;
+        nr = (int)runr;
+    };
+    // number of k < min(nl, nr) with lsp[k] < rsp[nr - 1 - k] (the condition is monotone in k), swaps of those pairs
+    auto pair_swaps = [&](int nl, int nr) -> int {
+        const int m = min(nl, nr);
+        if(tid == 0)
+            sh[0] = 0;
+        __syncthreads();
+        int mine = 0;
+        for(int k = tid; k < m; k += 256)
+            mine += (int)lsp[k] < (int)rsp[nr - 1 - k] ? 1 : 0;
+        for(int o = 32; o > 0; o >>= 1)
+            mine += __shfl_xor(mine, o);
+        if(lane == 0 && mine)
+            atomicAdd(&sh[0], mine);
+        __syncthreads();
+        const int K = sh[0];
+        for(int k = tid; k < K; k += 256)
+            swap_el((int)lsp[k], (int)rsp[nr - 1 - k]);
+        __syncthreads();
+        return K;
+    };
+    auto comp = [&](int a, int b) { return resp[a] > resp[b]; }; // KeypointResponseGreater on positions
+
+    // ---- std::nth_element(begin, begin + n_points - 1, end) = __introselect(..., 2 * __lg(n))
+    int first = 0, last = n;
+    const int nth = n_points - 1;
+    int depth = 2 * (31 - __builtin_clz((unsigned)n));
+    bool heap_done = false;
+    while(last - first > 3)
+    {
+        if(depth == 0)
+        {
+            // __heap_select(first, nth + 1, last) + iter_swap(first, nth): one thread, as the library does it
+            if(tid == 0)
+            {
+                const int len = nth + 1 - first;
+                auto el_r = [&](int i) -> float& { return resp[first + i]; };
+                auto el_k = [&](int i) -> uint32_t& { return keys[first + i]; };
+                auto push_heap = [&](int hole, int top, float vr, uint32_t vk) {
+                    int parent = (hole - 1) / 2;
+                    while(hole > top && el_r(parent) > vr)
+                    {
+                        el_r(hole) = el_r(parent);
+                        el_k(hole) = el_k(parent);
+                        hole = parent;
+                        parent = (hole - 1) / 2;
+                    }
+                    el_r(hole) = vr;
+                    el_k(hole) = vk;
+                };
+                auto adjust_heap = [&](int hole, int hlen, float vr, uint32_t vk) {
+                    const int top = hole;
+                    int second = hole;
+                    while(second < (hlen - 1) / 2)
+                    {
+                        second = 2 * (second + 1);
+                        if(el_r(second) > el_r(second - 1))
+                            second--;
+                        el_r(hole) = el_r(second);
+                        el_k(hole) = el_k(second);
+                        hole = second;
+                    }
+                    if((hlen & 1) == 0 && second == (hlen - 2) / 2)
+                    {
+                        second = 2 * (second + 1);
+                        el_r(hole) = el_r(second - 1);
+                        el_k(hole) = el_k(second - 1);
+                        hole = second - 1;
+                    }
+                    push_heap(hole, top, vr, vk);
+                };
+                if(len >= 2) // __make_heap
+                    for(int parent = (len - 2) / 2;; --parent)
+                    {
+                        adjust_heap(parent, len, el_r(parent), el_k(parent));
+                        if(parent == 0)
+                            break;
+                    }
+                for(int i = nth + 1; i < last; ++i)
+                    if(resp[i] > resp[first]) // __pop_heap(first, middle, i)
+                    {
+                        const float vr = resp[i];
+                        const uint32_t vk = keys[i];
+                        resp[i] = resp[first];
+                        keys[i] = keys[first];
+                        adjust_heap(0, len, vr, vk);
+                    }
+                swap_el(first, nth);
+            }
+            __syncthreads();
+            heap_done = true;
+            break;
+        }
+        --depth;
+        // __unguarded_partition_pivot: median of (first + 1, mid, last - 1) to first ...
+        if(tid == 0)
+        {
+            const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+            int m;
+            if(comp(a, b))
+                m = comp(b, c) ? b : comp(a, c) ? c : a;
+            else
+                m = comp(a, c) ? a : comp(b, c) ? c : b;
+            swap_el(first, m);
+        }
+        __syncthreads();
+        // ... then __unguarded_partition(first + 1, last, pivot = *first)
+        const float pv = resp[first];
+        int nl, nr;
+        rank2(first + 1, last, [&](float v) { return !(v > pv); }, [&](float v) { return !(pv > v); }, nl, nr);
+        const int K = pair_swaps(nl, nr);
+        // where the left pointer stops next: the next original left stopper if it lies before the last swapped right position,
+        // else that position (it holds a left stopper now)
+        int cut;
+        if(K < nl && (K == 0 || (int)lsp[K] < (int)rsp[nr - K]))
+            cut = (int)lsp[K];
+        else
+            cut = (int)rsp[nr - K]; // = rsp[nr - 1 - (K - 1)]; K >= 1 here (the median guarantees a left stopper)
+        __syncthreads(); // lsp / rsp are rewritten by the next pass
+        if(cut <= nth)
+            first = cut;
+        else
+            last = cut;
+    }
+    if(!heap_done)
+    {
+        // __insertion_sort(first, last) on at most three elements
+        if(tid == 0)
+            for(int i = first + 1; i < last; ++i)
+            {
+                const float vr = resp[i];
+                const uint32_t vk = keys[i];
+                if(vr > resp[first])
+                {
+                    for(int j = i; j > first; --j)
+                        resp[j] = resp[j - 1], keys[j] = keys[j - 1];
+                    resp[first] = vr;
+                    keys[first] = vk;
+                }
+                else
+                {
+                    int j = i;
+                    while(vr > resp[j - 1])
+                    {
+                        resp[j] = resp[j - 1];
+                        keys[j] = keys[j - 1];
+                        --j;
+                    }
+                    resp[j] = vr;
+                    keys[j] = vk;
+                }
+            }
+        __syncthreads();
+    }
+    // ---- std::partition(begin + n_points, end, response >= ambiguous): the k-th element from the left that fails with the
+    //      k-th from the right that passes, while the former lies left of the latter; the new end = n_points + #passing
+    const float amb = resp[n_points - 1];
+    int nf, np;
+    rank2(n_points, n, [&](float v) { return !(v >= amb); }, [&](float v) { return v >= amb; }, nf, np);
+    pair_swaps(nf, np);
+    return n_points + np;
+}
+
 // The body of k_cv_select on one (level, frame): `keys` holds the level's n keypoints (any order) and is sorted in place,
 // `kept` / `resp` receive the survivors of the first retainBest and their Harris responses (kept may alias keys: the
 // compaction only writes positions it has already read).  Force-inlined into two callers so that in the common case
 // every array is a known LDS object.
+template <class IDX>
 __device__ __forceinline__ void cv_select_run(uint32_t* keys, uint32_t* kept, float* resp, int n, int quota, const uint8_t* img,
                                               int pitch, uint32_t* sel, float* sresp, uint32_t* sel_cnt, uint32_t* hist,
-                                              uint32_t* wsum, int& s_thr, uint32_t* sorted_out)
+                                              uint32_t* wsum, int& s_thr, uint32_t* sorted_out, int std_order, IDX* lsp, IDX* rsp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // The tile kernel appended the level's keypoints in arrival order; FAST's own order — the order everything
@@ -514,6 +738,33 @@ __device__ __forceinline__ void cv_select_run(uint32_t* keys, uint32_t* kept, fl
         return (int)running;
     };
 
+    if(std_order)
+    {
+        // the reference's order (a GCC build): both retainBest calls as libstdc++ runs them, in place on (keys, resp)
+        __syncthreads();
+        for(int i = tid; i < n; i += 256)
+            resp[i] = (float)kp_score(keys[i]); // KeyPoint::response after FAST
+        __syncthreads();
+        const int m1 = retain_best_std<IDX>(keys, resp, n, 2 * quota, lsp, rsp, wsum, &s_thr);
+        __syncthreads();
+        for(int i = tid; i < m1; i += 256)
+        {
+            const uint32_t p = keys[i];
+            resp[i] = harris_at(img, pitch, kp_x(p), kp_y(p));
+        }
+        __syncthreads();
+        const int m2 = retain_best_std<IDX>(keys, resp, m1, quota, lsp, rsp, wsum, &s_thr);
+        __syncthreads();
+        for(int i = tid; i < m2; i += 256)
+        {
+            const uint32_t p = keys[i];
+            sel[i] = pack_kp(kp_x(p) - kBorder, kp_y(p) - kBorder, kp_score(p));
+            sresp[i] = resp[i];
+        }
+        if(tid == 0)
+            *sel_cnt = (uint32_t)m2;
+        return;
+    }
     // 1. retainBest(2 * quota) by FAST score (integer 1..255): threshold = the (2 quota)-th largest score
     int thr = 0;
     if(n > 2 * quota)
@@ -586,6 +837,7 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
     __shared__ int s_thr;
     __shared__ uint32_t l_keys[KP];
     __shared__ float l_resp[KP];
+    __shared__ uint16_t l_lsp[KP], l_rsp[KP]; // stopper ranks of retain_best_std
     // Workgroups go to the 8 XCDs round-robin by linear id = frame * n_levels + blockIdx.x: with level = blockIdx.x and the
     // usual 8 levels XCD 0 would get every level-0 pair (the heaviest: thousands of keys to sort) and XCD 7 every level-7
     // one; rotating the level by the frame index gives every XCD the same mix.
@@ -612,11 +864,13 @@ __global__ __launch_bounds__(256) void k_cv_select(const uint8_t* __restrict__ p
         __syncthreads();
         // a sort stage is a barrier + LDS traffic here; on the global arrays it was a round trip to L2 (55 stages for
         // 1024 keypoints: the whole kernel ran at ~250 us per workgroup)
-        cv_select_run(l_keys, l_keys, l_resp, n, quota, img, lv.pitch, sel, sresp, a.sel_cnt + slot, hist, wsum, s_thr, cand);
+        cv_select_run<uint16_t>(l_keys, l_keys, l_resp, n, quota, img, lv.pitch, sel, sresp, a.sel_cnt + slot, hist, wsum, s_thr, cand,
+                                a.std_order, l_lsp, l_rsp);
     }
-    else
-        cv_select_run(cand, a.tmp_kp + slot * (size_t)a.cand_cap, a.tmp_resp + slot * (size_t)a.cand_cap, n, quota, img,
-                      lv.pitch, sel, sresp, a.sel_cnt + slot, hist, wsum, s_thr, nullptr);
+    else // (global arrays; the stopper ranks of the library-order form borrow tmp_kp and — until the final emission — sel)
+        cv_select_run<uint32_t>(cand, a.std_order ? cand : a.tmp_kp + slot * (size_t)a.cand_cap, a.tmp_resp + slot * (size_t)a.cand_cap, n,
+                                quota, img, lv.pitch, sel, sresp, a.sel_cnt + slot, hist, wsum, s_thr, nullptr, a.std_order,
+                                a.tmp_kp + slot * (size_t)a.cand_cap, sel);
 }
 
 void launch_cv_select(const uint8_t* d_pyr, const Geometry& g, const CvSelectArgs& a, int frame0, int n_frames,

@@ -1157,6 +1157,7 @@ void mso_cvorb_default_params(mso_cvorb_params* p)
     p->n_levels = 8;
     p->edge_threshold = 31;
     p->fast_threshold = 20;
+    p->order = MSO_ORDER_LIBSTDCXX;
 }
 
 /* orb.cpp: getScale(level, firstLevel = 0, scaleFactor) = (float)std::pow(scaleFactor, (double)level) with the
@@ -1308,6 +1309,257 @@ void mso_cvorb_descriptor(const uint8_t* blurred, int step, int x, int y, float 
 #undef CV_VALUE
 }
 
+/* ---- KeyPointsFilter::retainBest in the ORDER a GCC build leaves (features2d/src/keypoint.cpp -> libstdc++) ----------------
+ * retainBest = std::nth_element(begin, begin + n - 1, end, KeypointResponseGreater()), then std::partition(begin + n, end,
+ * response >= keypoints[n - 1].response), then resize: which elements survive is defined by the standard (the SET
+ * {response >= the n-th largest}), where they end up is not — it is whatever the library's introselect and partition do.
+ * The reference is built with GCC (its CI and conan profile), i.e. libstdc++, whose algorithms have been the same since
+ * GCC 4.9 (bits/stl_algo.h, bits/stl_heap.h): restated here function by function on an array of (response, payload index)
+ * pairs, `comp(a, b)` = a.response > b.response.  tests/test_oracle_std_order.py compiles a C++ harness against the REAL
+ * <algorithm> of this image and compares the two on random, tie-heavy and adversarial inputs: this part of the oracle is
+ * pinned by the library itself. */
+typedef struct
+{
+    float r;     /* response */
+    int32_t idx; /* which keypoint */
+} mso_rk;
+#define RK_COMP(a, b) ((a).r > (b).r)
+static void rk_swap(mso_rk* a, mso_rk* b)
+{
+    const mso_rk t = *a;
+    *a = *b;
+    *b = t;
+}
+/* std::__push_heap (stl_heap.h), comparator __iter_comp_val */
+static void rk_push_heap(mso_rk* first, int hole, int top, mso_rk value)
+{
+    int parent = (hole - 1) / 2;
+    while(hole > top && RK_COMP(first[parent], value))
+    {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+/* std::__adjust_heap */
+static void rk_adjust_heap(mso_rk* first, int hole, int len, mso_rk value)
+{
+    const int top = hole;
+    int second = hole;
+    while(second < (len - 1) / 2)
+    {
+        second = 2 * (second + 1);
+        if(RK_COMP(first[second], first[second - 1]))
+            second--;
+        first[hole] = first[second];
+        hole = second;
+    }
+    if((len & 1) == 0 && second == (len - 2) / 2)
+    {
+        second = 2 * (second + 1);
+        first[hole] = first[second - 1];
+        hole = second - 1;
+    }
+    rk_push_heap(first, hole, top, value);
+}
+/* std::__make_heap */
+static void rk_make_heap(mso_rk* first, mso_rk* last)
+{
+    const int len = (int)(last - first);
+    if(len < 2)
+        return;
+    int parent = (len - 2) / 2;
+    for(;;)
+    {
+        const mso_rk value = first[parent];
+        rk_adjust_heap(first, parent, len, value);
+        if(parent == 0)
+            return;
+        parent--;
+    }
+}
+/* std::__pop_heap(first, last, result) */
+static void rk_pop_heap(mso_rk* first, mso_rk* last, mso_rk* result)
+{
+    const mso_rk value = *result;
+    *result = *first;
+    rk_adjust_heap(first, 0, (int)(last - first), value);
+}
+/* std::__heap_select */
+static int g_rk_heap_selects = 0; /* (test hook: how often the depth-limit branch ran) */
+int mso_std_heap_select_calls(void) { return g_rk_heap_selects; }
+static void rk_heap_select(mso_rk* first, mso_rk* middle, mso_rk* last)
+{
+    ++g_rk_heap_selects;
+    rk_make_heap(first, middle);
+    for(mso_rk* i = middle; i < last; ++i)
+        if(RK_COMP(*i, *first))
+            rk_pop_heap(first, middle, i);
+}
+/* std::__move_median_to_first(result, a, b, c) */
+static void rk_move_median_to_first(mso_rk* result, mso_rk* a, mso_rk* b, mso_rk* c)
+{
+    if(RK_COMP(*a, *b))
+    {
+        if(RK_COMP(*b, *c))
+            rk_swap(result, b);
+        else if(RK_COMP(*a, *c))
+            rk_swap(result, c);
+        else
+            rk_swap(result, a);
+    }
+    else if(RK_COMP(*a, *c))
+        rk_swap(result, a);
+    else if(RK_COMP(*b, *c))
+        rk_swap(result, c);
+    else
+        rk_swap(result, b);
+}
+/* std::__unguarded_partition(first, last, pivot) */
+static mso_rk* rk_unguarded_partition(mso_rk* first, mso_rk* last, const mso_rk* pivot)
+{
+    for(;;)
+    {
+        while(RK_COMP(*first, *pivot))
+            ++first;
+        --last;
+        while(RK_COMP(*pivot, *last))
+            --last;
+        if(!(first < last))
+            return first;
+        rk_swap(first, last);
+        ++first;
+    }
+}
+/* std::__unguarded_partition_pivot */
+static mso_rk* rk_unguarded_partition_pivot(mso_rk* first, mso_rk* last)
+{
+    mso_rk* mid = first + (last - first) / 2;
+    rk_move_median_to_first(first, first + 1, mid, last - 1);
+    return rk_unguarded_partition(first + 1, last, first);
+}
+/* std::__insertion_sort (with std::__unguarded_linear_insert) */
+static void rk_insertion_sort(mso_rk* first, mso_rk* last)
+{
+    if(first == last)
+        return;
+    for(mso_rk* i = first + 1; i != last; ++i)
+    {
+        if(RK_COMP(*i, *first))
+        {
+            const mso_rk val = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(mso_rk)); /* std::move_backward(first, i, i + 1) */
+            *first = val;
+        }
+        else
+        {
+            const mso_rk val = *i;
+            mso_rk* lastp = i;
+            mso_rk* next = i - 1;
+            while(RK_COMP(val, *next))
+            {
+                *lastp = *next;
+                lastp = next;
+                --next;
+            }
+            *lastp = val;
+        }
+    }
+}
+/* std::nth_element = std::__introselect(first, nth, last, 2 * std::__lg(last - first)) */
+static void rk_nth_element(mso_rk* first, mso_rk* nth, mso_rk* last)
+{
+    if(first == last || nth == last)
+        return;
+    int depth = 0;
+    for(long v = last - first; v > 1; v >>= 1)
+        ++depth; /* std::__lg */
+    depth *= 2;
+    while(last - first > 3)
+    {
+        if(depth == 0)
+        {
+            rk_heap_select(first, nth + 1, last);
+            rk_swap(first, nth); /* "Place the nth largest element in its final position." */
+            return;
+        }
+        --depth;
+        mso_rk* cut = rk_unguarded_partition_pivot(first, last);
+        if(cut <= nth)
+            first = cut;
+        else
+            last = cut;
+    }
+    rk_insertion_sort(first, last);
+}
+/* std::partition for bidirectional iterators (std::__partition(..., bidirectional_iterator_tag)), pred = response >= thr */
+static mso_rk* rk_partition_ge(mso_rk* first, mso_rk* last, float thr)
+{
+    for(;;)
+    {
+        for(;;)
+            if(first == last)
+                return first;
+            else if(first->r >= thr)
+                ++first;
+            else
+                break;
+        --last;
+        for(;;)
+            if(first == last)
+                return first;
+            else if(!(last->r >= thr))
+                --last;
+            else
+                break;
+        rk_swap(first, last);
+        ++first;
+    }
+}
+/* test hook (tests/test_oracle_std_order.py): retainBest's two library calls on n responses; order[] receives the payload
+ * indices of the survivors in their final places; returns how many survive */
+int mso_std_retain_best_order(const float* response, int n, int n_points, int32_t* order)
+{
+    mso_rk* a = (mso_rk*)malloc(sizeof(mso_rk) * (size_t)(n > 0 ? n : 1));
+    for(int i = 0; i < n; ++i)
+        a[i].r = response[i], a[i].idx = i;
+    int m = n;
+    if(n_points >= 0 && n > n_points)
+    {
+        if(n_points == 0)
+            m = 0;
+        else
+        {
+            rk_nth_element(a, a + n_points - 1, a + n);
+            const float ambiguous = a[n_points - 1].r;
+            m = (int)(rk_partition_ge(a + n_points, a + n, ambiguous) - a);
+        }
+    }
+    for(int i = 0; i < m; ++i)
+        order[i] = a[i].idx;
+    free(a);
+    return m;
+}
+/* KeyPointsFilter::retainBest on the oracle's keypoint records, libstdc++ order */
+static int retain_best_std(mso_cand* kp, int n, int n_points)
+{
+    if(n_points < 0 || n <= n_points)
+        return n;
+    float* r = (float*)malloc(sizeof(float) * (size_t)n);
+    int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    mso_cand* tmp = (mso_cand*)malloc(sizeof(mso_cand) * (size_t)n);
+    for(int i = 0; i < n; ++i)
+        r[i] = kp[i].response, tmp[i] = kp[i];
+    const int m = mso_std_retain_best_order(r, n, n_points, order);
+    for(int i = 0; i < m; ++i)
+        kp[i] = tmp[order[i]];
+    free(r);
+    free(order);
+    free(tmp);
+    return m;
+}
+
 /* KeyPointsFilter::retainBest as a SET: keep every element whose response is >= the n-th largest (ties kept);
  * stable (raster order preserved).  Returns the new count. */
 static int retain_best(mso_cand* kp, int n, int n_points)
@@ -1349,12 +1601,14 @@ int mso_cvorb_level_keypoints(const uint8_t* img, int w, int h, const mso_cvorb_
     for(int i = 0; i < n; ++i)
         if(out[i].x >= (float)e && out[i].x < (float)(w - e) && out[i].y >= (float)e && out[i].y < (float)(h - e))
             out[k++] = out[i];
-    n = retain_best(out, k, 2 * quota); /* HARRIS_SCORE: keep 2x, orb.cpp computeKeyPoints */
+    /* p->order: MSO_ORDER_LIBSTDCXX = the order a GCC build of the reference leaves (default), MSO_ORDER_RASTER = the kept
+     * set in FAST's raster order (what the standard alone defines) */
+    n = p->order == MSO_ORDER_RASTER ? retain_best(out, k, 2 * quota) : retain_best_std(out, k, 2 * quota); /* HARRIS_SCORE: keep 2x, orb.cpp computeKeyPoints */
     if(stage == 0)
         return n;
     for(int i = 0; i < n; ++i)
         out[i].response = mso_harris_response(img, w, cv_round_f(out[i].x), cv_round_f(out[i].y));
-    return retain_best(out, n, quota);
+    return p->order == MSO_ORDER_RASTER ? retain_best(out, n, quota) : retain_best_std(out, n, quota);
 }
 
 int mso_cvorb_detect(const uint8_t* bgr, int W, int H, const mso_cvorb_params* p, int max_out, float* xy, uint8_t* desc,

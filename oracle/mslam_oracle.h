@@ -111,10 +111,11 @@ void mso_backproject(const uint16_t* depth, int width, int height, float factor,
  * = toGrayScale + cv::ORB::create(1000)->detectAndCompute.  Everything below the call site is OpenCV 4.8.1
  * (features2d/src/orb.cpp, imgproc resize INTER_LINEAR_EXACT, KeyPointsFilter), not in the reference tree:
  * restated from the published algorithm, PARITY UNPINNED.
- * Deliberate differences from the reference, both documented in DESIGN.md:
- *  - output ORDER: retainBest() uses std::nth_element + std::partition, so the reference's order inside a level
- *    is implementation-defined; the kept SET is well defined (response >= the n-th largest, ties kept).  The oracle
- *    emits each level in FAST's raster order (y, then x);
+ * Notes:
+ *  - output ORDER: retainBest() uses std::nth_element + std::partition, so the order inside a level is whatever the C++
+ *    library of the build does; the kept SET is defined by the standard (response >= the n-th largest, ties kept).  The
+ *    reference is built with GCC: `order` = MSO_ORDER_LIBSTDCXX (default) reproduces libstdc++'s introselect / partition
+ *    step by step (pinned against the real <algorithm> of this image); MSO_ORDER_RASTER keeps FAST's raster order (y, x);
  *  - cos/sin of the keypoint angle are the correctly rounded float values ((float)cos((double)a) from the host libm's
  *    double routines) instead of the host libm's cosf/sinf, whose last bit is implementation-defined; the product
  *    evaluates include/mslam_sincos.h, an independent implementation of the same correctly rounded values. */
@@ -125,7 +126,13 @@ typedef struct
     int n_levels;       /* 8                                   */
     int edge_threshold; /* 31                                  */
     int fast_threshold; /* 20                                  */
+    int order;          /* MSO_ORDER_LIBSTDCXX (default) / MSO_ORDER_RASTER: where retainBest leaves the survivors */
 } mso_cvorb_params;
+enum { MSO_ORDER_LIBSTDCXX = 0, MSO_ORDER_RASTER = 1 };
+/* test hook: KeyPointsFilter::retainBest's std::nth_element + std::partition as libstdc++ runs them, on n responses;
+ * order[] = payload indices of the survivors in their final places, returns their number */
+int mso_std_retain_best_order(const float* response, int n, int n_points, int32_t* order);
+int mso_std_heap_select_calls(void); /* how often introselect's depth-limit branch (heap_select) has run */
 void mso_cvorb_default_params(mso_cvorb_params* p);
 /* layerScale / layer sizes / per-level feature quota (orb.cpp getScale, detectAndCompute, computeKeyPoints) */
 void mso_cvorb_geometry(int W, int H, const mso_cvorb_params* p, int* w, int* h, float* scale, int* quota);

@@ -225,11 +225,23 @@ def backproject(depth, xy, factor=1.0 / 5000.0, focal=(525.0, 525.0), principal=
 # ---- cv::ORB detector mode (OrbOpenCvDetector, orb_feature.cpp:25,33-65) -------------------------------------
 class CvOrbParams(C.Structure):
     _fields_ = [("n_features", C.c_int), ("scale_factor", C.c_float), ("n_levels", C.c_int),
-                ("edge_threshold", C.c_int), ("fast_threshold", C.c_int)]
+                ("edge_threshold", C.c_int), ("fast_threshold", C.c_int), ("order", C.c_int)]
 
 
-def cvorb_params(n_features=1000, scale_factor=1.2, n_levels=8, edge_threshold=31, fast_threshold=20):
-    return CvOrbParams(n_features, scale_factor, n_levels, edge_threshold, fast_threshold)
+ORDER_LIBSTDCXX, ORDER_RASTER = 0, 1
+
+
+def cvorb_params(n_features=1000, scale_factor=1.2, n_levels=8, edge_threshold=31, fast_threshold=20, order=ORDER_LIBSTDCXX):
+    return CvOrbParams(n_features, scale_factor, n_levels, edge_threshold, fast_threshold, order)
+
+
+def std_retain_best_order(response, n_points):
+    """KeyPointsFilter::retainBest's std::nth_element + std::partition as libstdc++ runs them: indices of the survivors in
+    their final places"""
+    r = np.ascontiguousarray(response, np.float32)
+    order = np.empty(max(len(r), 1), np.int32)
+    m = lib().mso_std_retain_best_order(_p(r), len(r), int(n_points), _p(order))
+    return order[:m].copy()
 
 
 def cvorb_geometry(W, H, p):

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.lib()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.mslam_hip_abi_version() == 4   # 2: mslam_hip_params gained detector / n_features / edge_threshold; 3: debug_counts takes its row count;
+    assert lib.mslam_hip_abi_version() == 5   # 5: mslam_hip_set_cv_keypoint_order; 2: mslam_hip_params gained detector / n_features / edge_threshold; 3: debug_counts takes its row count;
     # 4: + mslam_hip_pnp_set_confidence (the PnP entry points now end on the 0.99 confidence bound by default), mslam_hip_pack_batch_dev, mslam_hip_packed_capacity
 
 

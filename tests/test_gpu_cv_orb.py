@@ -36,6 +36,30 @@ def test_cv_orb_stages(pkg, orc, cctx, bundled_frames):
         assert np.array_equal(got, np.stack([sel["x"], sel["y"], sel["response"]], 1)), "selection level %d" % l
 
 
+def test_cv_orb_keypoint_order_forms(pkg, orc, bundled_frames, synth_frames):
+    """the two keypoint orders of the mode: libstdc++'s (default: what a GCC build of the reference returns, so its keypoint ids
+    and match indices) and FAST's raster order — each against the oracle in the same order, the same set either way, and the
+    switch takes effect on a context that has already captured its single-frame graph"""
+    c = pkg.Context(width=640, height=480, max_batch=2, detector=pkg.DETECTOR_CV_ORB)
+    for f in (bundled_frames[0], synth_frames[1]):
+        lib = c.detect(f)
+        ref = orc.cvorb_detect(f, orc.cvorb_params(order=orc.ORDER_LIBSTDCXX))
+        for k in ("xy", "desc", "octave", "angle", "response"):
+            assert np.array_equal(lib[k], ref[k]), ("library order", k)
+        c.set_cv_keypoint_order(pkg.CV_ORDER_RASTER)
+        ras = c.detect(f)
+        ref = orc.cvorb_detect(f, orc.cvorb_params(order=orc.ORDER_RASTER))
+        for k in ("xy", "desc", "octave", "angle", "response"):
+            assert np.array_equal(ras[k], ref[k]), ("raster order", k)
+        c.set_cv_keypoint_order(pkg.CV_ORDER_LIBSTDCXX)
+        assert len(lib["xy"]) == len(ras["xy"]) and not np.array_equal(lib["xy"], ras["xy"])
+        key = lambda d: sorted(zip(d["octave"].tolist(), map(tuple, d["xy"].tolist()), map(bytes, d["desc"])))  # noqa: E731
+        assert key(lib) == key(ras)
+    with pytest.raises(pkg.MslamHipError):
+        c.set_cv_keypoint_order(7)
+    c.close()
+
+
 def test_cv_orb_detect_parity(orc, cctx, bundled_frames, synth_frames):
     p = orc.cvorb_params()
     for f in list(bundled_frames) + list(synth_frames[:3]):

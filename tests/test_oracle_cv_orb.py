@@ -113,7 +113,9 @@ def test_sincos_is_correctly_rounded_and_libm_is_close(orc):
 
 
 def test_level_selection_is_retain_best(orc, frame):
-    p = orc.cvorb_params()
+    """the kept SET of both retainBest calls (raster order makes it comparable with a plain threshold); the library order
+    (the default, tests/test_oracle_std_order.py) is a permutation of it"""
+    p = orc.cvorb_params(order=orc.ORDER_RASTER)
     pyr = orc.cvorb_pyramid(orc.gray(frame), p)
     w, h, s, q = orc.cvorb_geometry(640, 480, p)
     for l in (0, 3, 7):
@@ -133,6 +135,8 @@ def test_level_selection_is_retain_best(orc, frame):
             kp, hr = kp[keep], hr[keep]
         assert np.array_equal(st1["x"], kp["x"]) and np.array_equal(st1["y"], kp["y"]) and np.array_equal(st1["response"], hr)
         assert len(st1) >= min(q[l], len(st0))
+        lib1 = orc.cvorb_level_keypoints(img, orc.cvorb_params(), q[l], 1)   # default order: libstdc++'s
+        assert sorted(map(tuple, lib1.tolist())) == sorted(map(tuple, st1.tolist()))
 
 
 def test_detect_structure(orc, frame):

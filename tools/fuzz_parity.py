@@ -148,12 +148,14 @@ def main():
             if cv:
                 n = int(rng.choice([0, 50, 500, 1000, 3000]))
                 edge = int(rng.integers(19, 40))
-                desc.update(n=n, edge=edge)
+                order = int(rng.integers(2))   # 0: libstdc++'s retainBest order (the default), 1: raster
+                desc.update(n=n, edge=edge, order=order)
                 c = pkg.Context(width=W, height=H, detector=pkg.DETECTOR_CV_ORB, n_features=n, n_levels=levels,
                                 scale_factor=scale, ini_fast_thr=thr, edge_threshold=edge, max_keypoints=65535,
                                 max_candidates=262144)
+                c.set_cv_keypoint_order(order)
                 ref = orc.cvorb_detect(f, orc.cvorb_params(n_features=n, n_levels=levels, scale_factor=scale,
-                                                           fast_threshold=thr, edge_threshold=edge))
+                                                           fast_threshold=thr, edge_threshold=edge, order=order))
             else:
                 min_thr = int(rng.integers(2, thr + 1))
                 area = int(rng.choice([40, 150, 400, 1000, 4000]))
