@@ -68,7 +68,7 @@ def stage_of_kernel(name):
         if name.startswith(pre):
             return st
     return None
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_per_step.json")  # tools/summarize_counters.py
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_per_step.json")  # tools/summarize_counters.py
 K2000_MIN_AREA = 984   # 640x480: 1986 keypoints per frame on the synthetic stream (1000, the reference default: ~1890)
 CFG4_MIN_AREA = 6340   # 1280x720, 8 levels: ~2015 keypoints per frame
 CLOCK_HZ = 2.4e9  # MI355X max shader clock (MI355X_MICROARCH.md); the vector-ALU issue figures are quoted at this clock

@@ -5,7 +5,7 @@ A stage of the step is one or more kernels and several launches (the detector ru
 1000-frame step; the pyramid is one launch per level), so the unit that can be compared with `ms_per_step` and with
 the algorithmic bytes of a step is the SUM over all launches of the profiled run divided by the number of steps the
 profiled command ran (bench.py --steps S --warmup W --no-extras runs max(W, 1) + S steps).  bench.py reads the JSON
-(`profiles/r04_pmc_per_step.json`) for `roofline.traffic` = (2 x FETCH_SIZE + WRITE_SIZE) KB (the gfx950 factor 2 of
+(`profiles/r05_pmc_per_step.json`) for `roofline.traffic` = (2 x FETCH_SIZE + WRITE_SIZE) KB (the gfx950 factor 2 of
 MI355X_MICROARCH.md §HBM) and for `roofline.step_valu_issue`."""
 import collections
 import csv
