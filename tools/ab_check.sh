@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-5 kernel iteration: GPU parity suite on the new library, then old / new stage times (ab_libs/), optionally a TCP + TA pass
+# kernel iteration: GPU parity suite on ab_libs/new.so, then old / new stage times (ab_libs/), optionally TCP + TA + SQ passes (MEMPATH=1)
 TAG=${1:-r5c}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
