@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md, matrix cores)
-STAGE_KERNEL = {"pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "void mslam::k_gray_blur<true>",
-                "resize": "void mslam::k_resize_blur<false, N, true> (one launch per level)", "fast": "mslam::k_fast_cells",
+STAGE_KERNEL = {"pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "void mslam::k_gray_blur<true, 0>",
+                "resize": "void mslam::k_resize_blur<false, N, true, 0> (one launch per level)", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur2", "describe": "void mslam::k_describe<true>",
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
                 "backproject": "mslam::k_backproject"}
@@ -58,7 +58,8 @@ STAGE_PREFIXES = (("mslam::k_gray", "gray"), ("mslam::k_resize", "resize"),
                   ("mslam::k_backproject", "backproject"), ("mslam::k_pnp_gather", "pnp_gather"),
                   ("mslam::k_pnp_ransac", "pnp_ransac"), ("mslam::k_bow_descend", "bow_descend"),
                   ("mslam::k_bow_flat", "bow_descend"), ("mslam::k_bow_vector", "bow_vector"),
-                  ("mslam::k_bow_score", "bow_score"), ("mslam::k_bow_sum", "bow_score"))
+                  ("mslam::k_bow_score", "bow_score"), ("mslam::k_bow_sum", "bow_score"),
+                  ("mslam::k_merge_ratio", "ratio_compact"), ("mslam::k_denorm_selfcheck", "setup"))
 
 
 def stage_of_kernel(name):
@@ -392,7 +393,7 @@ def main():
     ts = torch.cuda.Stream()  # the context's stream is a torch stream: torch copies / collectives order against it
     cv = a.detector == "cvorb"
     if cv:
-        STAGE_KERNEL.update({"resize": "void mslam::k_resize_blur<true, N, true> (one launch per level)", "fast": "mslam::k_fast_tiles",
+        STAGE_KERNEL.update({"resize": "void mslam::k_resize_blur<true, N, true, 0> (one launch per level)", "fast": "mslam::k_fast_tiles",
                              "select": "mslam::k_cv_select"})
     ctx = pkg.Context(width=a.width, height=a.height, max_batch=B, n_levels=a.levels, min_node_area=a.min_area,
                       max_keypoints=min(32736, max(4096 * k_scale, 2 * a.n_features if cv else 0)),  # 32736: the matrix-core matcher's train range
