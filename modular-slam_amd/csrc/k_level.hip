@@ -82,8 +82,7 @@ __device__ __forceinline__ EdgeSel edge_selectors(int x0, int w)
 // the blur's register state of one lane: six (row, row+1) pair rows and the previous row's horizontal sums
 struct BlurRing
 {
-    uint32_t pr[6][4];
-    uint32_t hprev[4];
+    uint32_t pr[6][4]; // pr[p][j]: horizontal sums of rows (i - 1, i) of pixel j as a u16 pair, written when row i with (i + 5) % 6 == p arrives
 };
 
 // Feeds raw row i (i % 6 == PH) of the lane's column into the filter.  Returns true and the blurred dword of row i - 3
@@ -105,9 +104,11 @@ __device__ __forceinline__ uint32_t blur_feed(BlurRing& st, uint32_t B, const Ed
     hv[1] = __builtin_amdgcn_udot4(A2, k.ta[1], __builtin_amdgcn_udot4(B2, k.tb[1], __builtin_amdgcn_udot4(C2, k.tc[1], 0u, false), false), false);
     hv[2] = __builtin_amdgcn_udot4(A2, k.ta[2], __builtin_amdgcn_udot4(B2, k.tb[2], __builtin_amdgcn_udot4(C2, k.tc[2], 0u, false), false), false);
     hv[3] = __builtin_amdgcn_udot4(B2, k.tb[3], __builtin_amdgcn_udot4(C2, k.tc[3], 0u, false), false);
+    // pair (row i-1, row i): row i-1's sum is the high half of the pair written one row ago — v_alignbit takes it from there
+    // (no separate copy of the previous row's sums: four registers)
 #pragma unroll
     for(int j = 0; j < 4; ++j)
-        st.pr[(PH + 5) % 6][j] = st.hprev[j] | (hv[j] << 16); // pair (row i-1, row i)
+        st.pr[(PH + 5) % 6][j] = __builtin_amdgcn_alignbit(hv[j], st.pr[(PH + 4) % 6][j], 16);
     uint32_t out = 0;
     if(EMIT)
     {
@@ -122,9 +123,6 @@ __device__ __forceinline__ uint32_t blur_feed(BlurRing& st, uint32_t B, const Ed
         }
         out = __builtin_amdgcn_perm(acc[1], acc[0], 0x0C0C0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020C0Cu);
     }
-#pragma unroll
-    for(int j = 0; j < 4; ++j)
-        st.hprev[j] = hv[j];
     return out;
 }
 
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
     BlurRing st;
 #pragma unroll
     for(int j = 0; j < 4; ++j)
-        st.hprev[j] = 0;
+        st.pr[4][j] = 0; // (row 0 pairs with "row -1": never looked at, but defined)
     // one row: i = i0 + PH, PH = i % 6 (static); RAW: the row belongs to the block (rows 3 .. R+2), BLUR: i >= 6
     auto compute = [&](auto ph, auto emit, auto sraw, int i, bool raw, const Bgr3& w) {
         constexpr int PH = decltype(ph)::value;
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     BlurRing st;
 #pragma unroll
     for(int j = 0; j < 4; ++j)
-        st.hprev[j] = 0;
+        st.pr[4][j] = 0; // (row 0 pairs with "row -1": never looked at, but defined)
     HRow hA{}, hB{};
     int rowA = -1, rowB = -1; // wave-uniform: which source rows hA / hB hold
     // both source rows of every destination row are requested two rows ahead, unconditionally (static 3-deep ring: the
