@@ -718,8 +718,10 @@ def main():
                 dist.all_reduce(t_ex, op=dist.ReduceOp.MAX)
                 s_host = scores.cpu().numpy()
                 extras["exchange"] = {
-                    "what": "per batch: DBoW3 vectors of %d frames (k=10 L=%d vocabulary) -> pack -> ONE "
-                            "all_gather_into_tensor -> L1 scores of own frame t vs frame t of every stream" % (B, a.voc_levels),
+                    "what": "per batch: DBoW3 vectors of %d frames (k=10 L=%d vocabulary) -> pack -> %s -> L1 scores of own "
+                            "frame t vs frame t of every stream" % (B, a.voc_levels, "ONE all_gather_into_tensor" if
+                                                                      cross.granularity == "batch" else
+                                                                      "one all_gather_into_tensor per frame"),
                     "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                     "granularity": cross.granularity,
                     "collectives_per_batch": (cross.collectives - c0) / float(n_ex),
