@@ -340,14 +340,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         b0 = __float_as_uint(__uint_as_float(b0) + 32.f); // everything found so far is one tile older
         b1 = __float_as_uint(__uint_as_float(b1) + 32.f);
         }
+        // Running top-2 in bundles of four keys, 5 instructions per bundle instead of 8 (round 5: this update, not the matrix
+        // pipe, is what the kernel waits for).  With b0 >= b1 and two new keys x, y: the best of {b0, b1, x, y} is
+        // max3(b0, x, y), the runner-up max(b1, med3(b0, x, y)) — b1 <= b0 can never exceed the median of a triple that
+        // contains b0 unless it IS the runner-up — and the max with b1 can wait: two bundles' medians go into one max3.
+        // Exact: the top-2 of a set does not depend on the order its elements arrive in, and keys are distinct.
+        // (The builtins, not inline asm: the compiler must see these reads of an MFMA result to keep the MFMA -> VALU wait states.)
 #pragma unroll
-        for(int i = 0; i < 16; ++i)
+        for(int i = 0; i < 16; i += 4)
         {
-            // b0 >= b1: the median is the new runner-up.  The builtin, not inline asm: the compiler must see
-            // this read of an MFMA result to keep the MFMA -> VALU wait states.
-            b1 = __float_as_uint(
-                __builtin_amdgcn_fmed3f(__uint_as_float(b0), __uint_as_float(b1), __uint_as_float(key[i])));
-            b0 = max(b0, key[i]);
+            const uint32_t m01 = __float_as_uint(
+                __builtin_amdgcn_fmed3f(__uint_as_float(b0), __uint_as_float(key[i]), __uint_as_float(key[i + 1])));
+            b0 = max(max(b0, key[i]), key[i + 1]);
+            const uint32_t m23 = __float_as_uint(
+                __builtin_amdgcn_fmed3f(__uint_as_float(b0), __uint_as_float(key[i + 2]), __uint_as_float(key[i + 3])));
+            b0 = max(max(b0, key[i + 2]), key[i + 3]);
+            b1 = max(max(b1, m01), m23);
         }
     };
 
