@@ -382,6 +382,8 @@ void mslam_hip_destroy(mslam_hip_ctx* c)
         (void)hipHostFree(c->h_out);
     if(c->h_hm)
         (void)hipHostFree(c->h_hm);
+    if(c->h_stage)
+        (void)hipHostFree(c->h_stage);
     if(c->match_graph)
         (void)hipGraphExecDestroy(c->match_graph);
     for(auto& e : c->detect_graph)
@@ -1231,7 +1233,24 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     int rc = detect_prologue(c);
     if(rc)
         return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_stage, bgr, (size_t)width * height * 3, hipMemcpyHostToDevice, c->stream));
+    // The frame is copied by the CPU into page-locked, device-mapped memory and the gray kernel reads it from there over PCIe
+    // (its deep-prefetch instance has every row of a block in flight at once: one round trip per block).  A copy from the
+    // caller's pageable buffer blocks the host for the same CPU copy into the runtime's own staging area and only then starts
+    // a DMA of ~20 us in front of the first kernel: detect 164 -> 148 us.  MSLAM_HIP_ZERO_COPY_FRAME=0: the copy.
+    static const bool zero_copy = [] { const char* e = getenv("MSLAM_HIP_ZERO_COPY_FRAME"); return !e || atoi(e) != 0; }();
+    const uint8_t* frame_src = c->d_stage;
+    if(zero_copy)
+    {
+        if(!c->h_stage)
+        {
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (size_t)width * height * 3, hipHostMallocMapped));
+            HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_stage), c->h_stage, 0));
+        }
+        std::memcpy(c->h_stage, bgr, (size_t)width * height * 3);
+        frame_src = c->d_h_stage;
+    }
+    else
+        HIPCHK(c, hipMemcpyAsync(c->d_stage, bgr, (size_t)width * height * 3, hipMemcpyHostToDevice, c->stream));
     // The single-frame call is launch-bound (11 small kernels), so its fixed sequence — kernels + the result packing
     // kernel — is captured once per output set into a HIP graph and replayed.  With stage timing on, the plain path runs.
     if(!c->profiling && !c->inplace_timing && c->use_graph)
@@ -1241,7 +1260,7 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
         {
             hipGraph_t graph = nullptr;
             HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-            rc = enqueue_detect(c, c->d_stage, 1);
+            rc = enqueue_detect(c, frame_src, 1);
             if(!rc)
                 rc = enqueue_results();
             const hipError_t e = hipStreamEndCapture(c->stream, &graph);
@@ -1255,7 +1274,7 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     }
     else
     {
-        rc = enqueue_detect(c, c->d_stage, 1);
+        rc = enqueue_detect(c, frame_src, 1);
         if(rc)
             return rc;
         rc = enqueue_results();

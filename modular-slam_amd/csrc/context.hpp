@@ -86,6 +86,8 @@ struct mslam_hip_ctx
 
     // device working set (sized for max_batch frames)
     uint8_t* d_stage = nullptr; // one frame of BGR for the host-pointer entry point
+    uint8_t* h_stage = nullptr; // the same as page-locked, device-mapped host memory (zero-copy upload, MSLAM_HIP_ZERO_COPY_FRAME)
+    uint8_t* d_h_stage = nullptr;
     uint8_t* d_pyr = nullptr;
     uint8_t* d_blur = nullptr;
     mslam::BlurWave* d_blur_waves = nullptr; // k_blur2 wave descriptors of one frame
