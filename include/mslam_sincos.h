@@ -1,14 +1,17 @@
 /* mslam_sincos.h — the cos/sin used by the cv::ORB detector mode (orb_feature.cpp:25,40; OpenCV orb.cpp
  * computeOrbDescriptors: `angle *= (float)(CV_PI/180.f); float a = (float)cos(angle), b = (float)sin(angle);`).
  *
- * The reference gets these two floats from the host C library (cosf / sinf), whose last-bit behaviour is not
- * specified and differs between libm versions; a GPU cannot call it.  This routine evaluates cos / sin of the
- * float angle in IEEE double arithmetic (Cody-Waite reduction to [-pi/4, pi/4], Taylor polynomials to r^16 / r^15:
- * absolute error < 1e-15 for |x| <= 8) and rounds the result to float, i.e. it returns the correctly rounded
- * float value except where the exact result lies within 1e-15 of a rounding boundary (about one argument in 1e8).
- * Every operation is a single rounded double add / multiply / floor in a fixed order, so the host build
- * (gcc -ffp-contract=off) and the device build (hipcc -ffp-contract=off) produce identical bits.
- * tests/test_oracle_cv_orb.py measures how often this host's libm cosf / sinf differs from it.
+ * Inside namespace cv the unqualified cos(angle) of a float resolves, in a GCC / libstdc++ build, to the C library's DOUBLE
+ * function (the float overloads of <cmath> live in namespace std; cv's using-list does not take them) — the (float) casts in
+ * the source say the same: the reference computes (float)cos((double)angle).  A GPU cannot call the host library, so this
+ * routine evaluates cos / sin of the float angle in IEEE double arithmetic (Cody-Waite reduction to [-pi/4, pi/4], Taylor
+ * polynomials to r^16 / r^15: absolute error < 1e-15 for |x| <= 8) and rounds the result to float.  Every operation is a
+ * single rounded double add / multiply / floor in a fixed order, so the host build (gcc -ffp-contract=off) and the device
+ * build (hipcc -ffp-contract=off) produce identical bits — and the host build equals glibc 2.35's (float)cos((double)x) /
+ * (float)sin((double)x) for EVERY float in [0, 6.5] (1 087 373 313 arguments, oracle/sincos_check/sincos_exhaustive.c,
+ * profiles/r05_g_sincos_exhaustive.txt; tests/test_oracle_cv_orb.py runs every 97th).  The same library's float routines
+ * cosf / sinf — what a build that resolved to the float overloads would call — differ from it in the last bit for 0.14 % of
+ * the arguments.
  */
 #ifndef MSLAM_SINCOS_H_
 #define MSLAM_SINCOS_H_
