@@ -76,3 +76,72 @@ def test_hip_loads_a_real_dbow3_vocabulary(pkg, orc, bundled_frames):
     rw, rv = _oracle_vocabulary(orc, blob).bow_vector(d)
     assert np.array_equal(gw, rw) and np.array_equal(gv.view(np.uint64), rv.view(np.uint64))
     c.close()
+
+
+def _self_dump(orc, frames):
+    """A dump with the record names / layouts opencv_dump writes, filled from the oracle itself: exercises the comparison
+    tool (so that it cannot rot while no real dump is committed) — it pins nothing."""
+    dump = {}
+    for f in range(2):
+        F = "f%d_" % f
+        bgr = np.ascontiguousarray(frames[f])
+        gray = orc.gray(bgr)
+        dump[F + "gray"] = gray
+        pyr = orc.pyramid(gray, orc.params())
+        cp = orc.cvorb_params()
+        epyr = orc.cvorb_pyramid(gray, cp)
+        for l in range(1, 8):
+            dump[F + "linear_L%d" % l] = pyr[l]
+            dump[F + "exact_L%d" % l] = epyr[l]
+
+        def rows(k):
+            return np.stack([k["x"], k["y"], k["response"]], 1).astype(np.float32).reshape(-1, 3)
+        for l in (0, 3, 6):
+            dump[F + "blur_L%d" % l] = orc.gaussian_blur7(pyr[l])
+            dump[F + "fast20_L%d" % l] = rows(orc.fast(pyr[l], 20, cap=pyr[l].size // 4))
+        for i in range(2):
+            for j in range(9):
+                for thr in (20, 7):
+                    dump[F + "cell_%d_%d_t%d" % (i, j, thr)] = rows(
+                        orc.fast(gray[19 + 64 * i:19 + 64 * i + 70, 19 + 64 * j:19 + 64 * j + 70], thr))
+        d = orc.cvorb_detect(bgr, cp)
+        dump[F + "orb_keypoints"] = np.stack([d["xy"][:, 0], d["xy"][:, 1], d["response"], d["angle"],
+                                              d["octave"].astype(np.float32)], 1).astype(np.float32)
+        dump[F + "orb_descriptors"] = d["desc"].copy()
+    dump["fast_atan2"] = np.array([[orc.fast_atan2(float(y * 977), float(x * 1013)) for x in range(-40, 41)]
+                                   for y in range(-40, 41)], np.float32)
+    i0, i1, d0, d1 = orc.match_knn2_raw(dump["f1_orb_descriptors"], dump["f0_orb_descriptors"])
+    dump["knn2"] = np.stack([i0, d0, i1, d1], 1)
+    return dump
+
+
+def test_comparison_tool_on_a_self_dump(orc, bundled_frames):
+    """compare.py's own logic: a dump equal to the oracle passes with the row order recognised; the same keypoints in
+    another STL's order are an INFO line by default and a failure under --strict-order; a wrong descriptor is a failure."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "opencv_check"))
+    import compare
+    frames = [bundled_frames[0], bundled_frames[1]]
+    dump = _self_dump(orc, frames)
+    lines = []
+    assert compare.compare(dump, frames, out=lines.append) == 0, "\n".join(lines)
+    assert sum("orb keypoint order identical row order" in l and l.startswith("PASS") for l in lines) == 2
+
+    other = dict(dump)
+    kp, de = dump["f0_orb_keypoints"].copy(), dump["f0_orb_descriptors"].copy()
+    lvl0 = np.flatnonzero(kp[:, 4] == 0)
+    perm = np.arange(len(kp))
+    perm[lvl0[:2]] = lvl0[1::-1]                                  # swap two keypoints of level 0
+    other["f0_orb_keypoints"], other["f0_orb_descriptors"] = kp[perm], de[perm]
+    ref = np.stack(orc.match_knn2_raw(dump["f1_orb_descriptors"], other["f0_orb_descriptors"]), 1)
+    other["knn2"] = ref[:, [0, 2, 1, 3]]
+    lines = []
+    assert compare.compare(other, frames, out=lines.append) == 0, "\n".join(lines)
+    assert any(l.startswith("INFO") and "f0_orb keypoint order" in l for l in lines)
+    lines = []
+    assert compare.compare(other, frames, out=lines.append, strict_order=True) == 1
+    assert any(l.startswith("FAIL") and "f0_orb keypoint order" in l for l in lines)
+
+    broken = dict(dump)
+    broken["f1_orb_descriptors"] = dump["f1_orb_descriptors"].copy()
+    broken["f1_orb_descriptors"][5] ^= 0xFF
+    assert compare.compare(broken, frames, out=lambda *_: None) >= 1
