@@ -13,7 +13,7 @@
 // translation) instead of
 // cvFindExtrinsicCameraParams2's LM on (rvec, tvec).  The confidence of the call site (0.99, :57) is honoured the way
 // RANSACPointSetRegistrator::run does it: hypotheses are looked at in their order, every new best one lowers the
-// number of iterations to log(1 - confidence) / log(1 - w^m) (w = its inlier share, m = 4 sample points here; OpenCV's
+// number of iterations to log(1 - confidence) / log(1 - w^m) (w = its inlier share, m = 5: the model points cv::solvePnPRansac samples for this call, kPnpModelPoints below; OpenCV's
 // RANSACUpdateNumIters, cvRound and all), and the loop ends there — the winner is the best of the hypotheses
 // 0 .. niters-1, exactly what the sequential loop returns.  tests/ pin it against ground-truth poses and an
 // independent numpy oracle.
