@@ -306,6 +306,104 @@ def cpu_baseline(frames, params_kw, seconds, cv=False, n_features=1000):
     return out
 
 
+def cfg4_multi_rank_leg(a, pkg, synth, torch, dist, rank, world, dev, red_dev, W4=1280, H4=720, B4=250, n_steps=8):
+    """cfg4 of BASELINE.json at world > 1: every rank extracts + matches its OWN 1280x720 stream (seed
+    1234 + 100 * rank), builds the DBoW3 vectors of the batch, and the exchange — pack, ONE all_gather_into_tensor per batch
+    (or one per frame), cross-stream L1 scores — runs INSIDE the timed step on the communication stream.  Barrier +
+    synchronize on both sides, MAX over ranks; keypoints summed over ranks.  After the timed region (never inside it) every
+    rank checks the HIP cross scores of two frames against the CPU oracle's L1 score on the vectors exactly as they were
+    transmitted (the oracle is the checker here, nothing it computes is timed or reported as a rate)."""
+    import __graft_entry__ as graft
+    from modular_slam_amd.multi_stream import CrossStreamLoopCandidates, set_dwords, unpack_set
+    f4 = synth.make_stream(B4, W4, H4, seed=1234 + 100 * rank)
+    d4 = torch.from_numpy(f4).cuda()
+    dd4 = torch.from_numpy(np.ascontiguousarray(
+        np.stack([synth.make_depth(1, W4, H4, seed=1234 + 100 * rank)[0]] * B4)).view(np.int16)).cuda()
+    area4 = -(-W4 * H4 // (640 * 480))
+    ts4 = torch.cuda.Stream()
+    ctx4 = pkg.Context(width=W4, height=H4, max_batch=B4, n_levels=8, min_node_area=CFG4_MIN_AREA,
+                       max_keypoints=min(8192, 4096 * area4), max_candidates=16384 * area4, device=dev, stream=ts4.cuda_stream)
+    ctx4.bow_load(synth.make_vocabulary(10, a.voc_levels, seed=77))
+    ctx4.bow_db_reserve(32 * B4)
+    cross4 = CrossStreamLoopCandidates(k_max=2048, granularity=a.exchange_granularity)
+
+    def step4(i):
+        ctx4.detect_batch_dev(d4.data_ptr(), B4)
+        ctx4.match_batch_dev(0.7, True)
+        ctx4.backproject_batch_dev(dd4.data_ptr())
+        ctx4.bow_batch_dev(True)
+        return cross4.step_gpu(ctx4, ts4, B4)
+
+    def settle4():
+        cross4.finish(ts4)
+        ctx4.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def reduce(x, op):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    for i in range(2):
+        step4(i)
+    settle4()
+    kp4 = int(pkg.read_device(ctx4, ctx4.batch_view().count, (B4,), np.int32).sum())
+    c0 = cross4.collectives
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        scores = step4(i)
+    settle4()
+    dt = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
+    n_coll = cross4.collectives - c0
+    kp_all = reduce(kp4, dist.ReduceOp.SUM)
+    # the exchange alone (pack + gather + cross scores of the last batch), on the streams the step uses
+    n_ex = 5
+    t0 = time.perf_counter()
+    for i in range(n_ex):
+        scores = cross4.step_gpu(ctx4, ts4, B4)
+    settle4()
+    dt_ex = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
+    # ---- oracle check, outside every timed region: own frames 0 and B4-1 against frame t of EVERY stream, from the gathered
+    # buffer as it arrived on this rank
+    orc = graft.load_oracle()
+    _, gathered, _ = cross4.last
+    s_host = scores.cpu().numpy()
+    sets = [unpack_set(gathered[r], B4, cross4.k_max) for r in range(world)]
+    mw, mv, mn = sets[rank]
+    checked, ok = [], True
+    for t in (0, B4 - 1):
+        for r in range(world):
+            w2, v2, n2 = sets[r]
+            exp = orc.bow_score_l1(mw[t, :mn[t]], mv[t, :mn[t]], w2[t, :n2[t]], v2[t, :n2[t]])
+            ok = ok and bool(exp == s_host[t, r])
+        checked.append(t)
+    ok = ok and bool(mn.min() > 0) and bool((s_host[:, rank] > 0.99).all())
+    all_ok = reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) == 1.0
+    out = {"workload": "cfg4: %d independent synthetic 1280x720 RGB-D streams (one per rank, seed 1234 + 100 x rank, %d distinct "
+                       "frames each), 8 levels, min-area %d, extract + knn-2 match + back-projection + DBoW3 (k=10, L=%d) "
+                       "vectors / scores / inverted-file adds + the cross-stream exchange (pack, all_gather_into_tensor, "
+                       "cross scores) inside the step" % (world, B4, CFG4_MIN_AREA, a.voc_levels),
+           "value": kp_all * n_steps / dt, "unit": "keypoints/s", "n_gpus": world, "scaling": "weak",
+           "ms_per_step": dt / n_steps * 1e3, "frames_per_step_per_rank": B4, "steps": n_steps,
+           "keypoints_per_frame": round(kp_all / world / B4, 1),
+           "timing": "barrier + synchronize on both sides, MAX over ranks; keypoints summed over ranks",
+           "exchange": {"backend": dist.get_backend(), "world_size": world, "granularity": cross4.granularity,
+                        "k_max": cross4.k_max, "collectives_per_step": n_coll / float(n_steps),
+                        "bytes_per_rank_per_collective": cross4.bytes_per_collective,
+                        "bytes_per_rank_per_batch": 4 * set_dwords(B4, cross4.k_max),
+                        "ms_per_batch": dt_ex / n_ex * 1e3,
+                        "what": "mslam_hip_bow_pack_dev -> all_gather_into_tensor -> mslam_hip_bow_cross_score_packed_dev "
+                                "alone (MAX over ranks); inside the step it runs on the communication stream beside the next "
+                                "batch's extraction"},
+           "oracle_check": all_ok,
+           "oracle_check_what": "every rank, after the timed region: HIP cross scores of own frames %s against frame t of all %d "
+                                "streams == the CPU oracle's L1 score on the vectors as transmitted (f32 values); MIN over "
+                                "ranks" % (checked, world)}
+    ctx4.close()
+    return out
+
+
 def dry_run(a, rank, world):
     """launcher rehearsal without a GPU (MSLAM_BENCH_DRY=1, used by the CPU test of `--gpus N`): rendezvous, the
     barrier + MAX/SUM reductions of the real run, one JSON line from rank 0."""
@@ -324,7 +422,7 @@ def dry_run(a, rank, world):
         # the rank's packed BoW set per batch (modular_slam_amd/multi_stream.py), here 3 batches of 8 frames
         import __graft_entry__ as graft
         graft.load_package()
-        from modular_slam_amd.multi_stream import CrossStreamLoopCandidates, set_dwords
+        from modular_slam_amd.multi_stream import CrossStreamLoopCandidates, set_dwords, pack_vectors, unpack_set
         cross = CrossStreamLoopCandidates(k_max=2048)
         n_b, fr = 3, 8
         for b in range(n_b):
@@ -333,6 +431,46 @@ def dry_run(a, rank, world):
             assert got.shape[0] == world and all(int(got[r].view(-1)[0]) == r * 1000 + b for r in range(world))
         exchange = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                     "collectives_per_batch": cross.collectives / float(n_b), "bytes_per_rank_per_batch": 4 * set_dwords(fr, cross.k_max)}
+        # the cfg4 leg of the real run at world > 1, rehearsed on host tensors: per-rank BoW vectors (ragged counts) in the
+        # wire format, the per-batch collective, cross scores of own frame t against frame t of every stream (a numpy L1
+        # here; the HIP kernel on the GPU box), the oracle check on the vectors as transmitted, and the MIN / MAX / SUM
+        # reductions of cfg4_multi_rank_leg
+        orc = graft.load_oracle()
+        rng = np.random.default_rng(4321 + rank)
+        B4, cap = 6, 512
+        W = torch.zeros((B4, cap), dtype=torch.int32)
+        V = torch.zeros((B4, cap), dtype=torch.float64)
+        N = torch.zeros(B4, dtype=torch.int32)
+        for t_ in range(B4):
+            n_ = int(rng.integers(100, cap))
+            W[t_, :n_] = torch.from_numpy(np.sort(rng.choice(5000, n_, replace=False)).astype(np.int32))
+            v_ = rng.random(n_)
+            V[t_, :n_] = torch.from_numpy(v_ / v_.sum())
+            N[t_] = n_
+
+        def l1(w1, v1, w2, v2):
+            d = dict(zip(w2.tolist(), v2.tolist()))
+            acc = 0.0
+            for w_, x_ in zip(w1.tolist(), v1.tolist()):  # ascending word order, as the reference's std::map walk
+                if w_ in d:
+                    acc += abs(x_ - d[w_]) - abs(x_) - abs(d[w_])
+            return -acc / 2.0
+        c1 = cross.collectives
+        got4 = cross.step_with(W, V, N, l1)
+        sets4 = cross.all_gather_sets(pack_vectors(W, V, N, cross.k_max), n_frames=B4)
+        un4 = [unpack_set(sets4[r], B4, cross.k_max) for r in range(world)]
+        ok4 = True
+        for t_ in (0, B4 - 1):
+            for r in range(world):
+                exp = orc.bow_score_l1(un4[rank][0][t_, :N[t_]], un4[rank][1][t_, :N[t_]],
+                                       un4[r][0][t_, :un4[r][2][t_]], un4[r][1][t_, :un4[r][2][t_]])
+                ok4 = ok4 and abs(exp - got4[t_, r]) < 1e-12
+        okt = torch.tensor([1.0 if ok4 else 0.0], dtype=torch.float64)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        cfg4 = {"n_gpus": world, "exchange": {"backend": dist.get_backend(), "world_size": world,
+                                              "collectives_per_step": (cross.collectives - c1) / 2.0,
+                                              "bytes_per_rank_per_batch": 4 * set_dwords(B4, cross.k_max)},
+                "oracle_check": bool(okt.item() == 1.0)}
     if rank == 0:
         line = {"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "dist": {"backend": "gloo" if world > 1 else None, "world_size": world,
@@ -340,6 +478,7 @@ def dry_run(a, rank, world):
                 "t_max": float(t.item()), "units": float(k.item())}
         if exchange is not None:
             line["exchange"] = exchange
+            line["cfg4"] = cfg4
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
@@ -730,6 +869,15 @@ def main():
                     "ms_per_batch_incl_bow": float(t_ex.item()) / n_ex * 1e3,
                     "self_score_min": float(s_host[:, rank].min()),
                     "cross_score_max": float(np.delete(s_host, rank, 1).max())}
+
+            if world > 1 and not a.no_legs and not cv:
+                # ---- cfg4 as BASELINE.json states it: every rank its own 1280x720 stream, DBoW3 scoring and the all-gather of
+                # the BoW sets + cross-stream scores INSIDE the step (feed point: rgbd_feature_frontend.cpp:176)
+                try:
+                    extras["cfg4"] = cfg4_multi_rank_leg(a, pkg, synth, torch, dist, rank, world, dev, red_dev)
+                except Exception as e:  # noqa: BLE001 - recorded; a rank that fails here leaves its peers to the watchdog
+                    extras["cfg4_error"] = "%s: %s" % (type(e).__name__, e)
+                    torch.cuda.synchronize()
 
             if world == 1 and rank == 0:
                 # PCIe-inclusive: frames + depth start in pinned host memory, double-buffered H2D on a copy stream while

@@ -102,6 +102,7 @@ class CrossStreamLoopCandidates:
         self._pack_done = None
         self.collectives = 0   # all-gathers issued (one per batch, or one per frame with granularity="frame")
         self.bytes_per_collective = 0  # payload each rank contributed to the last collective
+        self.last = None
 
     # ---- the exchange step -------------------------------------------------------------------
     def all_gather_sets(self, local_set, out=None, n_frames=None):
@@ -158,6 +159,7 @@ class CrossStreamLoopCandidates:
             self._comm = torch.cuda.Stream()
         local, gathered, scores = self._buffers(n_frames)
         self._slot ^= 1
+        self.last = (local, gathered, scores)  # the buffer set of this call (valid after finish())
         # these buffers were last used two steps ago by the communication stream
         ctx_stream.wait_stream(self._comm)
         ctx.bow_pack_dev(self.k_max, local.data_ptr())            # on the context's stream

@@ -30,6 +30,10 @@ def test_gpus_2_spawns_two_ranks():
     # the loop-candidate exchange ran over the process group: ONE collective per batch, as the first real RCCL run must show
     assert j["exchange"]["world_size"] == 2 and j["exchange"]["collectives_per_batch"] == 1.0
     assert j["exchange"]["bytes_per_rank_per_batch"] == 4 * 8 * (2 * 2048 + 1)
+    # the cfg4 leg that the real run adds at world > 1 (every rank its own stream, the exchange inside the step, cross scores
+    # checked against the oracle on the vectors as transmitted): rehearsed on host tensors over the same process group
+    assert j["cfg4"]["n_gpus"] == 2 and j["cfg4"]["oracle_check"] is True
+    assert j["cfg4"]["exchange"]["world_size"] == 2 and j["cfg4"]["exchange"]["collectives_per_step"] == 1.0
 
 
 def test_single_rank_needs_no_launcher():

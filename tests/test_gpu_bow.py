@@ -166,6 +166,105 @@ def test_rccl_world1_exchange(pkg, orc, synth_frames):
         r.returncode, r.stdout[-600:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_cfg4_two_rank_exchange(backend):
+    """cfg4 of BASELINE.json between TWO ranks (feed point rgbd_feature_frontend.cpp:176): every rank extracts its
+    own 1280x720 stream (seed 1234 + 100 * rank), builds the DBoW3 vectors, packs them, ONE all_gather_into_tensor moves the sets
+    and the HIP kernel scores own frame t against frame t of both streams; every rank compares ALL its cross scores with the
+    oracle's L1 score on the oracle's own vectors of both streams (f32 values as transmitted).
+    `nccl` (= RCCL over xGMI): needs two GPUs, one rank per GPU — skipped on a one-GPU box, this is the test the first multi-GPU
+    box activates.  `gloo`: the rehearsal a one-GPU box can run — both ranks on GPU 0, the collective through host memory, the
+    same pack / score kernels and the same checks.  The ranks are child processes started before this process touches the GPU
+    API for them; a timeout kills them and FAILS."""
+    import subprocess
+    import textwrap
+    import torch
+    if backend == "nccl":
+        import torch.distributed as dist
+        if not dist.is_nccl_available():
+            pytest.skip("this torch build has no nccl (RCCL) backend")
+        if torch.cuda.device_count() < 2:
+            pytest.skip("the RCCL two-rank cfg4 exchange needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    code = textwrap.dedent("""
+        import os, sys, numpy as np, torch, torch.distributed as dist
+        backend = %r
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dev = rank if backend == "nccl" else 0
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
+        import __graft_entry__ as g, synth
+        pkg = g.load_package(); orc = g.load_oracle()
+        from modular_slam_amd.multi_stream import CrossStreamLoopCandidates
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
+        print("INIT_OK", rank, flush=True)
+        W, H, B = 1280, 720, 3
+        blob = synth.make_vocabulary(10, 3)
+        V = orc.Vocabulary(blob)
+        P = orc.params(min_size=6340)
+        streams = [synth.make_stream(B, W, H, seed=1234 + 100 * r) for r in range(world)]
+        sent = []
+        for r in range(world):
+            row = []
+            for t in range(B):
+                w, v = V.bow_vector(orc.detect(streams[r][t], P)["desc"])
+                row.append((w, v.astype(np.float32).astype(np.float64)))
+            sent.append(row)
+        ts = torch.cuda.Stream()
+        c = pkg.Context(width=W, height=H, max_batch=B, max_keypoints=8192, max_candidates=16384 * 3, min_node_area=6340,
+                        device=dev, stream=ts.cuda_stream)
+        c.bow_load(blob)
+        d = torch.from_numpy(streams[rank]).cuda()
+        for gran, per_batch in (("batch", 1), ("frame", B)):
+            x = CrossStreamLoopCandidates(k_max=2048, granularity=gran)
+            assert x.world == world and x.rank == rank
+            for rep in range(3):
+                c.detect_batch_dev(d.data_ptr(), B)
+                c.bow_batch_dev(False)
+                sc = x.step_gpu(c, ts, B)
+            x.finish(ts); c.sync()
+            sc = sc.cpu().numpy()
+            assert sc.shape == (B, world)
+            for t in range(B):
+                for r in range(world):
+                    exp = orc.bow_score_l1(*sent[rank][t], *sent[r][t])
+                    assert sc[t, r] == exp, (gran, rank, t, r, sc[t, r], exp)
+            assert x.collectives == 3 * per_batch, (gran, x.collectives)
+            assert np.delete(sc, rank, 1).max() < sc[:, rank].min()     # another stream never scores like the own frame
+            print("GRAN_OK", rank, gran, x.bytes_per_collective, flush=True)
+        dist.barrier(); dist.destroy_process_group(); c.close()
+        print("CFG4_RANK_OK", rank, flush=True)
+    """ % (backend, ROOT, ROOT))
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      env=env))
+    outs = []
+    import time as _t
+    deadline = _t.time() + 420
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=max(1.0, deadline - _t.time()))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, e = p.communicate()
+            pytest.fail("the two-rank cfg4 exchange (%s) did not finish within 420 s (ranks killed): stdout %r stderr %r" % (
+                backend, (o or "")[-800:], (e or "")[-1500:]))
+        outs.append((p.returncode, o, e))
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and ("CFG4_RANK_OK %d" % r) in o, "rank %d exit code %s\nstdout: %s\nstderr: %s" % (r, rc, o[-600:], e[-2000:])
+
+
 def test_cross_stream_scores(pkg, orc, synth_frames):
     """the multi-GPU exchange step on one rank: HIP pack -> all-gather (trivial at world 1) -> HIP scoring of the
     gathered sets on the communication stream, against the oracle on the vectors as transmitted (f32 values);
