@@ -44,14 +44,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # 157 TF fp32 spec = this x 2 (packed) x 2 (fma)).
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense FP4 via v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md, matrix cores)
-STAGE_KERNEL = {"pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "void mslam::k_gray_blur<true, 0>",
+STAGE_KERNEL = {"levels": "void mslam::k_level_chain<false, 8, true, W, C> (gray + blur and every resize + blur level, one launch per chunk)",
+                "pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "void mslam::k_gray_blur<true, 0>",
                 "resize": "void mslam::k_resize_blur<false, N, true, 0> (one launch per level)", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur2", "describe": "void mslam::k_describe<true>",
                 "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
                 "backproject": "mslam::k_backproject"}
 POPCOUNT_KERNEL = "void mslam::k_match_knn2<8, 1, 8>"
 # kernel name (rocprofv3, without the argument list) -> stage of the step; a stage can be several kernels / launches
-STAGE_PREFIXES = (("mslam::k_gray", "gray"), ("mslam::k_resize", "resize"),
+STAGE_PREFIXES = (("mslam::k_level_chain", "levels"), ("mslam::k_gray", "gray"), ("mslam::k_resize", "resize"),
                   ("mslam::k_blur", "blur"), ("mslam::k_fast", "fast"), ("mslam::k_zero_u32", "fast"),
                   ("mslam::k_quadtree", "quadtree"), ("mslam::k_cv_select", "select"), ("mslam::k_describe", "describe"),
                   ("mslam::k_match_knn2", "match_knn2"), ("mslam::k_ratio_compact", "ratio_compact"),
@@ -196,6 +197,8 @@ def stage_bytes(ctx, B, n_kp, n_cand, voc_k=10, voc_L=6, db_entries=64):
         # writes level l twice
         "gray": B * (3 * px[0] + 2 * px[0]),
         "resize": B * sum(px[l - 1] + 2 * px[l] for l in range(1, len(px))),
+        # the one-launch level chain (k_level_chain) = gray + resize
+        "levels": B * (3 * px[0] + 2 * px[0]) + B * sum(px[l - 1] + 2 * px[l] for l in range(1, len(px))),
         "fast": B * P + 4 * n_cand,
         "quadtree": 4 * n_cand + 4 * n_kp,
         "blur": B * 2 * P,

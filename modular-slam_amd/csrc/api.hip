@@ -681,6 +681,20 @@ static int create_impl(mslam_hip_ctx* c)
             const char* k = getenv("MSLAM_HIP_LEVEL_K6");
             const char* ks = getenv("MSLAM_HIP_LEVEL_K6_SMALL");
             c->level_k6_small = ks ? std::max(0, atoi(ks)) : 0; // a handful of frames: 2-row blocks (a wave walks 8 rows instead of 14)
+            {
+                // the one-launch level chain (k_level_chain; off by default: measured equal in place, 4 % slower alone — DESIGN.md §8.1):
+                // MSLAM_HIP_LEVEL_CHAIN=1, frames per workgroup, waves per workgroup (4 or 8), longest row block
+                const char* lc = getenv("MSLAM_HIP_LEVEL_CHAIN");
+                const char* lf = getenv("MSLAM_HIP_LEVEL_CHAIN_FRAMES");
+                const char* lw = getenv("MSLAM_HIP_LEVEL_CHAIN_WAVES");
+                const char* lk = getenv("MSLAM_HIP_LEVEL_CHAIN_K6");
+                c->level_chain = lc ? atoi(lc) : 0;
+                c->level_chain_frames = lf ? std::max(1, std::min(64, atoi(lf))) : 2;
+                c->level_chain_waves = lw ? atoi(lw) : 8;
+                if(c->level_chain_waves != 4)
+                    c->level_chain_waves = 8;
+                c->level_chain_k6 = lk ? std::max(1, std::min(9, atoi(lk))) : 9;
+            }
             c->level_k6 = k ? std::max(1, atoi(k)) : 9; // 9 -> 56-row blocks: the halo re-reads cost 11 % instead of 19 % (32 rows); the step time is the same
             const bool fits = (p.width & 3) == 0 && (double)B * p.width * p.height * 3 < 4294967296.0 &&
                               (double)B * g.slab < 4294901760.0 /* below k_level.hip's kDropLane */ && (size_t)B * (p.width / 4) < (1u << 22) && p.height >= 8;
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(256) void k_carry_prev(uint4* __restrict__ dst, con
 
 // one level l > 0 produced and blurred in one pass (k_level.hip)
 static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, const uint32_t* ycoef, int exact, int f0, int nf,
-                                int k6, hipStream_t cs)
+                                int k6, hipStream_t cs, ResizeBlurArgs* chain_out = nullptr)
 {
     const Geometry& g = c->geom;
     const LevelGeom &sl = g.lv[l - 1], &dl = g.lv[l];
@@ -893,6 +907,11 @@ static void enqueue_resize_blur(mslam_hip_ctx* c, int l, const int32_t* yofs, co
     ra.blur_tiled = g.blur_tiled;
     ra.always_load = nf < 8 ? 1 : 0;
     ra.bk = make_blur_k();
+    if(chain_out) // a level of the one-launch chain (k_level_chain picks its own rows per block)
+    {
+        *chain_out = ra;
+        return;
+    }
     launch_resize_blur(ra, cs);
 }
 
@@ -919,6 +938,30 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
         hipStream_t cs = n_chunks > 1 ? c->side[k] : s;
         if(n_chunks > 1)
             HIPCHK(c, hipStreamWaitEvent(cs, c->ev_fork, 0));
+        const bool cv_mode = c->p.detector == MSLAM_HIP_DETECTOR_CV_ORB;
+        // gray + every level of the chunk in ONE launch (k_level_chain): batches whose levels all come from k_level.hip
+        bool chained = false;
+        if(c->level_chain && !cv_mode && nf >= 8 && c->fused_levels == g.n_levels && g.n_levels <= kChainLevels && g.blur_tiled)
+        {
+            StageScope t(c, "levels", cs);
+            GrayBlurArgs ga{};
+            ga.bgr = d_bgr;
+            ga.pyr = c->d_pyr;
+            ga.blur = c->d_blur;
+            ga.W = g.W, ga.H = g.H, ga.pitch = g.lv[0].pitch;
+            ga.slab = g.slab;
+            ga.n_frames = nf, ga.frame0 = f0;
+            ga.quads = g.W / 4;
+            ga.inv_quads = 1.0f / (float)ga.quads;
+            ga.k6 = 1;
+            ga.blur_tiled = g.blur_tiled;
+            ga.bk = make_blur_k();
+            ResizeBlurArgs lv[kChainLevels - 1];
+            for(int l = 1; l < g.n_levels; ++l)
+                enqueue_resize_blur(c, l, c->d_rs_ofs + c->rs_y[l], c->d_rs_coef + c->rs_y[l], 0, f0, nf, k6_batch, cs, &lv[l - 1]);
+            chained = launch_level_chain(ga, lv, g.n_levels - 1, c->level_chain_frames, c->level_chain_waves, c->level_chain_k6, cs);
+        }
+        if(!chained)
         {
             StageScope t(c, "gray", cs);
             if(c->fused_levels >= 1)
@@ -940,7 +983,6 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
             else
                 launch_gray(d_bgr, c->d_pyr, g, f0, nf, cs);
         }
-        const bool cv_mode = c->p.detector == MSLAM_HIP_DETECTOR_CV_ORB;
         if(cv_mode)
         {
             // OrbOpenCvDetector (orb_feature.cpp:33-65 -> OpenCV orb.cpp detectAndCompute), see k_cvorb.hip
@@ -1012,6 +1054,7 @@ static int enqueue_detect(mslam_hip_ctx* c, const uint8_t* d_bgr, int n_frames)
         }
         else
         {
+        if(!chained)
         {
             StageScope t(c, "resize", cs);
             for(int l = 1; l < g.n_levels; ++l)

@@ -186,6 +186,19 @@ struct ResizeBlurArgs
     BlurK bk;
 };
 void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s);
+// k_level.hip: gray + blur and every resize + blur level of a batch in ONE launch (a small workgroup walks the levels of its
+// frames in sequence); false = this pyramid cannot take the chain (the caller launches per level)
+constexpr int kChainLevels = 8;
+struct LevelChainArgs
+{
+    GrayBlurArgs g;
+    ResizeBlurArgs lv[kChainLevels - 1];
+    int n_lv;           // resize levels (pyramid levels - 1)
+    int G;              // frames per workgroup
+    int n_groups, groups_per_xcd;
+    int frame0, n_frames;
+};
+bool launch_level_chain(const GrayBlurArgs& g, const ResizeBlurArgs* lv, int n_lv, int frames_per_group, int waves, int k6_max, hipStream_t s);
 // k_blur2: one descriptor per wave of a frame (level-uniform waves of 64 consecutive (band, strip) items)
 struct BlurWave
 {

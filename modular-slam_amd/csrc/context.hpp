@@ -94,6 +94,7 @@ struct mslam_hip_ctx
     int blur_wpf = 0;
     int fused_levels = 0;  // levels 0 .. fused_levels-1 are produced and blurred by k_level.hip; k_blur2 takes the rest
     int level_k6 = 9;      // k_level.hip: rows per block = 6 k6 + 2
+    int level_chain = 0, level_chain_frames = 2, level_chain_waves = 8, level_chain_k6 = 9; // k_level_chain (k_level.hip)
     int level_k6_small = 1; // the same for batches of fewer than 8 frames (latency: one wave's walk is the launch's duration)
     uint32_t* d_cell_cnt = nullptr;
     uint32_t* d_cell_kp = nullptr;

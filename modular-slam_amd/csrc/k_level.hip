@@ -171,14 +171,11 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
 // DEEP = N > 0: the launch is a handful of waves (the synchronous single-frame call) and lasts as long as ONE wave's walk, so
 // all N = R + 6 rows of the block are requested before the first is used (N x 3 registers) instead of two rows ahead: one
 // memory round trip per block instead of one per two rows.
+// the walk of ONE wave: wave gw of the launch's (frame, quad) items, row block `by`
 template <bool TILED, int DEEP>
-__global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
+__device__ __forceinline__ void gray_blur_wave(const GrayBlurArgs& a, const int gw, const int by)
 {
     const int lane = threadIdx.x & 63;
-    // XCD-aware wave numbering: workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is a multiple of 8, so the
-    // XCD of a workgroup is blockIdx.x & 7 for every row block).  Each XCD gets a contiguous eighth of the waves: waves that
-    // are neighbours in the image (shared 128-byte lines at their edges, shared halo rows between row blocks) meet in one L2.
-    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x & 7) * a.waves_per_xcd + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)));
     const int n_items = a.n_frames * a.quads;
     const int item_raw = gw * 62 - 1 + lane;
     if(gw * 62 >= n_items)
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
     const int f = (int)(((float)item + 0.5f) * a.inv_quads); // item / quads, exact for items < 2^22 (host check)
     const int q = item - f * a.quads;
     const int R = 6 * a.k6 + 2;
-    const int y0 = min((int)blockIdx.y * R, a.H - R); // the last block ends at the last row (host: R <= H)
+    const int y0 = min(by * R, a.H - R); // the last block ends at the last row (host: R <= H)
     const EdgeSel e = edge_selectors(4 * q, a.W);
     const uint32_t src_v = (uint32_t)(f + a.frame0) * (uint32_t)(a.W * a.H * 3) + 12u * (uint32_t)q;
     // Every lane stores every row, unconditionally: the compiler can then count the stores in its vmcnt waits and the
@@ -278,6 +275,16 @@ __global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
 #undef MSLAM_ROW
 }
 
+template <bool TILED, int DEEP>
+__global__ __launch_bounds__(256) void k_gray_blur(GrayBlurArgs a)
+{
+    // XCD-aware wave numbering: workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is a multiple of 8, so the
+    // XCD of a workgroup is blockIdx.x & 7 for every row block).  Each XCD gets a contiguous eighth of the waves: waves that
+    // are neighbours in the image (shared 128-byte lines at their edges, shared halo rows between row blocks) meet in one L2.
+    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x & 7) * a.waves_per_xcd + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)));
+    gray_blur_wave<TILED, DEEP>(a, gw, (int)blockIdx.y);
+}
+
 // ---- level l > 0: resize + blur --------------------------------------------------------------------------------------
 // The interpolation is k_resize_col's (host tables: per destination quad a 12-byte source window, v_perm selectors and
 // weight pairs; per destination row the source row and the weight pair).  Rows are walked in DESTINATION order here (the
@@ -299,17 +306,15 @@ struct HRow
 // no per-lane selects
 // DEEP = N > 0: as in k_gray_blur — both source-row windows of all N = R + 6 rows of the block are requested up front (the
 // single-frame launches, whose duration is one wave's walk: 6 N registers)
-template <bool EXACT, int NEED, bool TILED, int DEEP>
-__global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
+// the walk of ONE wave: wave gw of the launch's (frame, quad) items, row block `by`.  COH: the source level was written by
+// this very kernel (k_level_chain): its loads go past the CU's L1 (sc0).
+template <bool EXACT, int NEED, bool TILED, int DEEP, bool COH>
+__device__ __forceinline__ void resize_blur_wave(const ResizeBlurArgs& a, const int gw, const int by)
 {
     const int lane = threadIdx.x & 63;
-    // XCD-aware wave numbering: workgroups go to the 8 XCDs round-robin by linear id (gridDim.x is a multiple of 8, so the
-    // XCD of a workgroup is blockIdx.x & 7 for every row block).  Each XCD gets a contiguous eighth of the waves: waves that
-    // are neighbours in the image (shared 128-byte lines at their edges, shared halo rows between row blocks) meet in one L2.
-    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x & 7) * a.waves_per_xcd + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)));
     const int n_items = a.n_frames * a.quads;
     const int R = 6 * a.k6 + 2; // host: R + 6 <= 64 (the block's row table lives in lane registers), R <= dh
-    const int y0 = min((int)blockIdx.y * R, a.dh - R);
+    const int y0 = min(by * R, a.dh - R);
     // lane i keeps the table entry of the block's row i (destination row reflect(y0 - 3 + i)); loaded by ALL lanes before
     // any leaves (v_readlane reads lanes that have exited, too)
     const int my_row = reflect_row(y0 - 3 + min(lane, R + 5), a.dh);
@@ -338,13 +343,13 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
 
     const BufRsrc src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, -1, 0x00020000);
     auto load = [&](int sy) { // (buffer load: scalar row offset + vector lane offset, see k_gray_blur)
-        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(src_rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), 0);
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(src_rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), COH ? 1 : 0);
         return Raw3{v.x, v.y, v.z};
     };
     auto load_if = [&](int sy, bool need) {
         // (readfirstlane: the record count must be a scalar register for the compiler, else it wraps the load in a waterfall loop)
         const BufRsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_lv), 0, __builtin_amdgcn_readfirstlane(need ? -1 : 0), 0x00020000);
-        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), 0);
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)src_v, (int)((uint32_t)sy * (uint32_t)a.spitch), COH ? 1 : 0);
         return Raw3{v.x, v.y, v.z};
     };
     auto hinterp = [&](const Raw3& w) {
@@ -532,6 +537,122 @@ __global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
     MSLAM_ROW(0, true, false, R + 4, false);
     MSLAM_ROW(1, true, false, R + 5, false);
 #undef MSLAM_ROW
+}
+
+template <bool EXACT, int NEED, bool TILED, int DEEP>
+__global__ __launch_bounds__(256) void k_resize_blur(ResizeBlurArgs a)
+{
+    // XCD-aware wave numbering, as in k_gray_blur
+    const int gw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x & 7) * a.waves_per_xcd + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6)));
+    resize_blur_wave<EXACT, NEED, TILED, DEEP, false>(a, gw, (int)blockIdx.y);
+}
+
+// ---- the whole level chain of a group of frames in ONE launch (round 6) ------------------------------------------------
+// The per-level launches above are each a single, partly filled generation of waves: a launch lasts as long as one wave's
+// walk down its row block and the next level cannot start before the last wave of this one has drained (14 launches per
+// 1000-frame step).  Here a small workgroup takes G frames through gray + blur and every resize + blur level in sequence:
+// its waves deal the (column wave, row block) walks of a level among themselves, meet at a barrier (+ a workgroup-scope
+// fence: the level just written is read back through the L2, writer and reader share the CU) and go on to the next level.
+// Workgroups are independent, so a CU holds frames at different levels at the same time (the memory-bound level 0 of one
+// beside the issue-bound upper levels of another) and the launch has a steady state.  The walks are the ones above.
+template <bool EXACT, int NEED, bool TILED, int WAVES, bool COH>
+__global__ __launch_bounds__(WAVES * 64) void k_level_chain(LevelChainArgs ch)
+{
+    // groups contiguous per XCD (workgroups go to the XCDs round-robin by linear id)
+    const int grp = (int)(blockIdx.x & 7) * ch.groups_per_xcd + (int)(blockIdx.x >> 3);
+    if(grp >= ch.n_groups)
+        return; // (whole workgroup: before any barrier)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int f0 = grp * ch.G;
+    const int nf = min(ch.G, ch.n_frames - f0);
+    {
+        GrayBlurArgs a = ch.g;
+        a.frame0 = ch.frame0 + f0;
+        a.n_frames = nf;
+        const int R = 6 * a.k6 + 2;
+        const int nwx = (nf * a.quads + 61) / 62, nby = (a.H + R - 1) / R;
+#pragma unroll 1
+        for(int item = wave; item < nwx * nby; item += WAVES)
+        {
+            const int by = item / nwx;
+            gray_blur_wave<TILED, 0>(a, item - by * nwx, by);
+        }
+    }
+#pragma unroll 1
+    for(int l = 0; l < ch.n_lv; ++l)
+    {
+        // workgroup scope is enough — writer and reader waves share the CU: the stores are acknowledged by the L2 (vmcnt) before
+        // the barrier, the next level's loads go past the L1 when COH (a device-scope fence would write the whole L2 back)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        ResizeBlurArgs a = ch.lv[l];
+        a.frame0 = ch.frame0 + f0;
+        a.n_frames = nf;
+        const int R = 6 * a.k6 + 2;
+        const int nwx = (nf * a.quads + 61) / 62, nby = (a.dh + R - 1) / R;
+#pragma unroll 1
+        for(int item = wave; item < nwx * nby; item += WAVES)
+        {
+            const int by = item / nwx;
+            resize_blur_wave<EXACT, NEED, TILED, 0, COH>(a, item - by * nwx, by);
+        }
+    }
+}
+
+// rows per block of a chained level: the block height 6 k + 2 that minimises the longest wave's walk, (walks per wave) x (R + 6)
+static int chain_k6(int quads, int rows, int G, int waves, int k6_max)
+{
+    const long nwx = ((long)G * quads + 61) / 62;
+    int best = 1;
+    long best_cost = -1;
+    for(int k = 1; k <= k6_max && 6 * k + 2 <= rows; ++k)
+    {
+        const int R = 6 * k + 2;
+        const long items = nwx * ((rows + R - 1) / R);
+        const long cost = ((items + waves - 1) / waves) * (R + 6);
+        if(best_cost < 0 || cost <= best_cost)
+            best = k, best_cost = cost;
+    }
+    return best;
+}
+
+bool launch_level_chain(const GrayBlurArgs& g, const ResizeBlurArgs* lv, int n_lv, int frames_per_group, int waves, int k6_max, hipStream_t s)
+{
+    if(n_lv > kChainLevels - 1 || !g.blur_tiled)
+        return false;
+    LevelChainArgs ch{};
+    ch.g = g;
+    ch.G = frames_per_group;
+    ch.frame0 = g.frame0;
+    ch.n_frames = g.n_frames;
+    ch.n_lv = n_lv;
+    ch.g.k6 = chain_k6(g.quads, g.H, ch.G, waves, k6_max);
+    int need = 0;
+    for(int l = 0; l < n_lv; ++l)
+    {
+        if(lv[l].exact || !lv[l].blur_tiled)
+            return false;
+        ch.lv[l] = lv[l];
+        ch.lv[l].always_load = 0;
+        ch.lv[l].k6 = chain_k6(lv[l].quads, lv[l].dh, ch.G, waves, k6_max);
+        need |= lv[l].need_mask;
+    }
+    ch.n_groups = (g.n_frames + ch.G - 1) / ch.G;
+    ch.groups_per_xcd = (ch.n_groups + 7) / 8;
+    const dim3 grid(8 * ch.groups_per_xcd);
+    const bool n8 = (need & ~8) == 0;
+#define MSLAM_LC(N, W) hipLaunchKernelGGL((k_level_chain<false, N, true, W, true>), grid, dim3(W * 64), 0, s, ch)
+    if(waves == 8)
+    {
+        if(n8) MSLAM_LC(8, 8); else MSLAM_LC(15, 8);
+    }
+    else
+    {
+        if(n8) MSLAM_LC(8, 4); else MSLAM_LC(15, 4);
+    }
+#undef MSLAM_LC
+    return true;
 }
 
 void launch_resize_blur(const ResizeBlurArgs& a, hipStream_t s)

@@ -1,4 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -489,6 +491,44 @@ def test_pyramid_and_blur_forms(pkg, orc, bundled_frames, synth_frames, monkeypa
         c.close()
 
 
+@pytest.mark.parametrize("frames,waves", [("1", "4"), ("2", "8"), ("3", "8"), ("16", "4")])
+def test_level_chain_form(pkg, orc, bundled_frames, synth_frames, monkeypatch, frames, waves):
+    """the one-launch level chain (k_level_chain, MSLAM_HIP_LEVEL_CHAIN=1: a workgroup of `waves` waves takes `frames` frames
+    through gray + blur and every resize + blur level, a workgroup-scope fence + barrier between levels): every plane and
+    blurred plane of the first, a middle and the last frame of an 11-frame batch (the last group is short, frame boundaries
+    fall inside waves) and the detections, against the oracle; sizes with one and several column waves per frame"""
+    import torch
+    import synth
+    monkeypatch.setenv("MSLAM_HIP_LEVEL_CHAIN", "1")
+    monkeypatch.setenv("MSLAM_HIP_LEVEL_CHAIN_FRAMES", frames)
+    monkeypatch.setenv("MSLAM_HIP_LEVEL_CHAIN_WAVES", waves)
+    p = orc.params()
+    for W, H in ((640, 480), (332, 208), (1284, 724)):
+        n = 11 if W < 1000 else 8
+        batch = synth.make_stream(n, W, H, seed=W + 7)
+        if W == 640:
+            batch[3] = bundled_frames[0]
+        c = pkg.Context(width=W, height=H, max_batch=n, max_keypoints=16384, max_candidates=65536)
+        c.set_profiling(2)
+        c.detect_batch_dev(torch.from_numpy(batch).cuda().data_ptr(), n)
+        c.sync()
+        assert "levels" in {nm for nm, _ in c.stage_times()}, "the chain did not take this batch"
+        c.set_profiling(0)
+        v, K = c.batch_view(), 16384
+        cnt = pkg.read_device(c, v.count, (n,), np.int32)
+        desc = pkg.read_device(c, v.desc, (n, K, 32), np.uint8)
+        xy = pkg.read_device(c, v.xy, (n, K, 2), np.float32)
+        for f in sorted({0, 3, n // 2, n - 1}):
+            pyr = orc.pyramid(orc.gray(batch[f]), p)
+            for l in range(8):
+                assert np.array_equal(c.debug_image(pkg.DBG_PYRAMID, f, l), pyr[l]), "frame %d level %d" % (f, l)
+                assert np.array_equal(c.debug_image(pkg.DBG_BLURRED, f, l), orc.gaussian_blur7(pyr[l])), "blur %d %d" % (f, l)
+            ref = orc.detect(batch[f], p)
+            assert cnt[f] == len(ref["xy"])
+            assert np.array_equal(desc[f, :cnt[f]], ref["desc"]) and np.array_equal(xy[f, :cnt[f]], ref["xy"])
+        c.close()
+
+
 @pytest.mark.parametrize("tiled", ["1", "0"])
 def test_blurred_slab_tiled_and_in_rows(pkg, orc, bundled_frames, synth_frames, monkeypatch, tiled):
     """the blurred slab in 64 x 2 pixel tiles (the default when every level is fused; k_describe<true>) and in rows
@@ -554,6 +594,8 @@ def test_stage_timing_modes_do_not_change_results(pkg, orc, synth_frames):
     dev = torch.from_numpy(np.stack([synth_frames[i % 6] for i in range(16)])).cuda()
     # (the blur has no launch of its own when every level is produced and blurred by the fused level kernels)
     expected = {"gray", "resize", "fast", "quadtree", "describe", "match_knn2", "ratio_compact"}
+    if os.environ.get("MSLAM_HIP_LEVEL_CHAIN", "0") not in ("", "0"):  # gray + resize are one launch then (k_level_chain)
+        expected = (expected - {"gray", "resize"}) | {"levels"}
     for mode in (1, 2):
         c.set_profiling(mode)
         c.detect_batch_dev(dev.data_ptr(), 16)   # 16 frames: two chunks on two streams in mode 2
