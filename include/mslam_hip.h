@@ -314,8 +314,24 @@ size_t mslam_hip_packed_capacity(const mslam_hip_ctx* ctx, int n_frames, int wit
  * and translation of the world -> camera transform, OpenCV's convention) are the extrinsic guess on input when
  * use_extrinsic_guess is non-zero, and the result on output; inliers (n bytes, may be NULL) is the consensus mask of
  * the best hypothesis.  Returns MSLAM_HIP_E_NO_MODEL when no hypothesis reaches 4 inliers (solvePnPRansac == false).
- * The minimal solver, sampling and refinement are this library's own (P3P, splitmix64 with `seed`, damped
- * Gauss-Newton): see csrc/k_pnp.hip for what is and is not the same as OpenCV's internals.  The call site's confidence
+ * Against cv::solvePnPRansac as OpenCV 4.8.1 runs it for this call (restated piece by piece in
+ * oracle/mslam_cv_pnp_oracle.py from the library's published algorithm), of the four pieces
+ *   1 sampler          DEVIATES: splitmix64 counter streams keyed by (`seed`, hypothesis) — hypotheses are independent of
+ *                      each other, which is what lets them run in parallel — not cv::RNG((uint64)-1)'s one sequential
+ *                      multiply-with-carry stream drawing 5-point subsets;
+ *   2 minimal solver   DEVIATES: P3P on three points, the fourth picks the branch — not EPnP on five points;
+ *   3 consensus loop   SAME: squared reprojection error <= 5^2 px, a hypothesis replaces the best one only with MORE inliers
+ *                      (and at least 4), RANSACUpdateNumIters(confidence, outlier share, 5 model points) after every new
+ *                      best one, hypotheses looked at in order (the kernel scores them in parallel rounds and walks each
+ *                      round in order);
+ *   4 final refit      SAME objective and set (reprojection error over the inliers of the best hypothesis, all in double),
+ *                      other minimiser and start: damped Gauss-Newton to convergence from the caller's guess (or the best
+ *                      hypothesis) — OpenCV runs <= 20 Levenberg-Marquardt steps from the LAST hypothesis its loop
+ *                      evaluated (the callback writes every hypothesis into the guess buffers).
+ * So the hypothesis sequence differs, the result the call site consumes (success, consensus set, refined pose,
+ * cv_ransac_pnp.cpp:59-83) agrees wherever the consensus set is unambiguous: tests/test_pnp.py compares both entry
+ * points with that oracle (masks equal, rvec / tvec within 1e-6 on noise-free scenes with 0 - 60 % outliers; within
+ * 0.02 degrees / 2 mm with pixel noise, where borderline points may fall either side of 5 px).  The call site's confidence
  * (0.99, :57) ends the loop as in OpenCV's RANSACPointSetRegistrator: every new best hypothesis lowers the iteration
  * count to log(1 - confidence) / log(1 - w^5) (w = its inlier share; 5 = the model points cv::solvePnPRansac samples for this
  * call's flags, although this library's own minimal sample is 3 + 1 points), hypotheses beyond it are not looked at. */

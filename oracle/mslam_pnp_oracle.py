@@ -1,4 +1,6 @@
-"""numpy oracle of the RANSAC PnP step (reference call site cv_ransac_pnp.cpp:56-57).
+"""numpy oracle of the RANSAC PnP step (reference call site cv_ransac_pnp.cpp:56-57) — the KERNEL's
+hypothesis sequence (same sampler, P3P); the oracle that follows OpenCV's own algorithm instead (cv::RNG, EPnP, LM) is
+oracle/mslam_cv_pnp_oracle.py, and tests/test_pnp.py compares the HIP solver with both.
 
 TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: cv::solvePnPRansac's internals (EPnP on 5-point samples, cv::RNG, LM of
 cvFindExtrinsicCameraParams2) live in OpenCV, which is not in the reference tree; what IS fixed by the call site is the

@@ -123,6 +123,39 @@ def test_gpu_pnp_matches_ground_truth_and_oracle(pkg):
 
 
 @pytest.mark.gpu
+def test_gpu_pnp_against_the_opencv_algorithm_oracle(pkg):
+    """the HIP solver against oracle/mslam_cv_pnp_oracle.py — cv::solvePnPRansac restated from OpenCV's published algorithm
+    (cv::RNG 5-point subsets, EPnP, float reprojection errors, RANSACUpdateNumIters, LM from the last hypothesis), which shares
+    neither sampler nor minimal solver nor refinement with the kernel (P3P on splitmix64 samples, damped Gauss-Newton).  What
+    must agree all the same is what the call site consumes (cv_ransac_pnp.cpp:59-83): success, the consensus set and the pose
+    refined on it.  Noise-free scenes with far outliers (every all-inlier hypothesis of either solver explains exactly the true
+    inliers): masks equal, rvec / tvec within 1e-6.  Noisy scenes: masks may differ in a few borderline points, poses within
+    0.02 degrees / 2 mm of each other."""
+    import mslam_cv_pnp_oracle as cvo
+    from test_oracle_cv_pnp import scene as cv_scene
+    c = pkg.Context(width=0, height=0)
+    for seed, outl in ((31, 0.0), (32, 0.2), (33, 0.45), (34, 0.6)):
+        obj, img, rvec, t, good = cv_scene(seed, n=500, outliers=outl, noise=0.0)
+        ref = cvo.solve_pnp_ransac(obj, img, CAM)
+        got = c.pnp_ransac(obj, img, CAM[:2], CAM[2:], seed=seed)
+        assert ref["ok"] and got is not None
+        r, tv, mask = got
+        assert np.array_equal(ref["mask"], good) and np.array_equal(mask, good), (seed, mask.sum(), ref["mask"].sum(), good.sum())
+        assert np.abs(r - ref["rvec"]).max() < 1e-6 and np.abs(tv - ref["tvec"]).max() < 1e-6, (seed, r - ref["rvec"], tv - ref["tvec"])
+    for seed, outl in ((41, 0.1), (42, 0.4)):
+        obj, img, rvec, t, good = cv_scene(seed, n=500, outliers=outl, noise=0.4)
+        # the call site passes the previous pose as the guess: both entry points take it, both end in the consensus optimum
+        ref = cvo.solve_pnp_ransac(obj, img, CAM, rvec0=rvec + 0.01, tvec0=t + 0.02)
+        r, tv, mask = c.pnp_ransac(obj, img, CAM[:2], CAM[2:], rvec=rvec + 0.01, tvec=t + 0.02, seed=seed)
+        assert (mask != ref["mask"]).sum() <= 0.02 * len(mask) and not (mask & ~good).any() and not (ref["mask"] & ~good).any()
+        assert rot_err(po.rodrigues(r), po.rodrigues(ref["rvec"])) < 0.02 and np.linalg.norm(tv - ref["tvec"]) < 2e-3
+    rng = np.random.default_rng(5)
+    o, i2 = rng.normal(size=(50, 3)).astype(np.float32) + [0, 0, 5], rng.uniform(0, 480, (50, 2)).astype(np.float32)
+    assert not cvo.solve_pnp_ransac(o, i2, CAM, thr=0.05)["ok"] and c.pnp_ransac(o, i2, CAM[:2], CAM[2:], reprojection_error=0.05) is None
+    c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_pnp_batch_on_device_results(pkg):
     """the batched device form: correspondences of every frame gathered on the device from the matches and the previous
     frame's back-projected points; one PnP per frame.  A fronto-parallel plane at 2 m seen by a camera that moves
