@@ -70,7 +70,7 @@ def stage_of_kernel(name):
         if name.startswith(pre):
             return st
     return None
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_per_step.json")  # tools/summarize_counters.py
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06_pmc_per_step.json")  # tools/summarize_counters.py
 K2000_MIN_AREA = 984   # 640x480: 1986 keypoints per frame on the synthetic stream (1000, the reference default: ~1890)
 CFG4_MIN_AREA = 6340   # 1280x720, 8 levels: ~2015 keypoints per frame
 CLOCK_HZ = 2.4e9  # MI355X max shader clock (MI355X_MICROARCH.md); the vector-ALU issue figures are quoted at this clock
@@ -100,6 +100,36 @@ def pmc_profile():
     return j["stages"], float(meta.get("frames_per_step", 1000)), (
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes), summed over the launches of a step, "
         "(2*FETCH + WRITE) KB, %s" % os.path.basename(PMC_PROFILE))
+
+
+MEMPATH_PROFILE = os.path.join(ROOT, "profiles", "r06_mempath.json")  # tools/mempath_counters.sh + tools/summarize_mempath.py
+
+
+def busy_fracs(stage):
+    """(TA busy fraction, vector-ALU issue fraction, note) of a stage ALONE on the GPU, from the committed memory-path passes
+    (`TA_TA_BUSY_sum` / `SQ_INSTS_VALU`, each with `GRBM_GUI_ACTIVE` in its own rocprofv3 pass over the serialized stage run):
+    counter sums over every launch of the stage's kernels, TA busy cycles per CU (and vector instructions x 4 cycles per SIMD)
+    over the kernels' own active cycles per XCD — no clock assumption.  (None, None, reason) when there is no profile or it was
+    collected on other kernel sources."""
+    try:
+        j = json.load(open(MEMPATH_PROFILE))
+        meta = j["_meta"]
+    except (OSError, KeyError, ValueError):
+        return None, None, "no memory-path profile committed (%s)" % os.path.basename(MEMPATH_PROFILE)
+    if meta.get("csrc_sha") != csrc_sha():
+        return None, None, "stale: %s was collected on kernel sources %s, this build is %s" % (
+            os.path.basename(MEMPATH_PROFILE), meta.get("csrc_sha"), csrc_sha())
+    out = []
+    for key in ("ta_busy_frac_sums", "valu_issue_frac_sums"):
+        x = g = 0.0
+        for name, row in j["kernels"].items():
+            if stage_of_kernel(name if name.startswith("mslam::") else "void " + name) == stage and key in row:
+                x += row[key]["counter"]
+                g += row[key]["GRBM_GUI_ACTIVE"]
+        scale = 1.0 / 256.0 if key.startswith("ta") else 4.0 / 1024.0
+        out.append(x * scale / (g / 8.0) if g > 0 else None)
+    return out[0], out[1], "rocprofv3 --pmc TA_TA_BUSY_sum / SQ_INSTS_VALU with GRBM_GUI_ACTIVE (separate passes), %s" % os.path.basename(
+        MEMPATH_PROFILE)
 
 
 def pmc_traffic(stage, frames_per_step):
@@ -658,16 +688,22 @@ def main():
         # `binding_limit` says what actually binds the dominant kernel: the larger of its HBM fraction and its vector-ALU
         # issue fraction (both alone)
         bound = "hbm"
-        binding = "hbm"
-        if valu_frac_alone is not None and frac_alone is not None and valu_frac_alone > frac_alone:
-            binding = "valu-issue"
-        limiter = "not HBM (see DESIGN.md §4: every stage but gray is issue- or latency-bound)"
-        if valu_frac_alone is not None:
-            limiter = ("vector-ALU issue %.0f %% of the kernel's duration alone on the GPU (SQ_INSTS_VALU x 4 cycles at 2.4 GHz, "
-                       "%s) against %.0f %% of the HBM peak for its algorithmic bytes" % (
-                           100 * valu_frac_alone, os.path.basename(PMC_PROFILE), 100 * frac_alone))
+        # the unit that binds the dominant kernel: the largest of its three busy fractions alone on the GPU — HBM (algorithmic
+        # bytes over the peak), vector-ALU issue and the texture-address path (TA busy).  The last two come from the committed
+        # memory-path passes over the kernel's own active cycles when they match these sources (no clock assumption), else
+        # the vector figure falls back to SQ_INSTS_VALU x 4 cycles at the nominal 2.4 GHz
+        ta_busy, valu_busy, busy_note = busy_fracs(dom)
+        cands = {"hbm": frac_alone, "valu-issue": valu_busy if valu_busy is not None else valu_frac_alone, "texture-address (TA)": ta_busy}
+        cands = {k: v for k, v in cands.items() if v is not None}
+        binding = max(cands, key=cands.get) if cands else "hbm"
+        limiter = "not HBM (see DESIGN.md §4: every stage but gray is issue-, TA- or latency-bound)"
+        if cands:
+            limiter = "alone on the GPU: " + ", ".join("%s %.0f %%" % (k, 100 * v) for k, v in sorted(cands.items(), key=lambda kv: -kv[1]))
+            limiter += " (%s)" % (busy_note if ta_busy is not None else
+                                  "vector issue = SQ_INSTS_VALU x 4 cycles at 2.4 GHz, %s; TA busy unavailable: %s" % (
+                                      os.path.basename(PMC_PROFILE), busy_note))
             if dom == "describe":
-                limiter += "; the rest of its time is the L2 -> LDS window gathers (DESIGN.md §4.6)"
+                limiter += "; 4.25 LDS-DMA window fetches per keypoint through the texture addresser (DESIGN.md §4.6)"
         # per-stage table: every stage alone on the GPU against both roofs, and its counter traffic over its algorithmic bytes
         stage_table = {}
         for k, ms_alone in ser.items():
@@ -678,11 +714,18 @@ def main():
             row["valu_issue_frac_alone"] = round(vk / ms_alone, 3) if vk is not None else None
             tk, _ = pmc_traffic(k, B)
             row["traffic_over_algorithmic"] = round(tk / sb[k], 2) if tk is not None and sb[k] else None
+            ta_k, va_k, _ = busy_fracs(k)
+            row["ta_busy_frac_alone"] = round(ta_k, 3) if ta_k is not None else None
+            row["valu_issue_frac_alone_counter_cycles"] = round(va_k, 3) if va_k is not None else None
             stage_table[k] = row
         roofline = {"kernel": kern, "stage": dom, "bound": bound, "binding_limit": binding, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "frac_alone": round(frac_alone, 4) if frac_alone is not None else None,
                     "valu_issue_frac_alone": round(valu_frac_alone, 3) if valu_frac_alone is not None else None,
+                    # from the memory-path passes, over the kernel's own active cycles (GRBM_GUI_ACTIVE): TA busy and vector issue
+                    "ta_busy_frac_alone": round(ta_busy, 3) if ta_busy is not None else None,
+                    "valu_issue_frac_alone_counter_cycles": round(valu_busy, 3) if valu_busy is not None else None,
+                    "busy_fracs_source": busy_note,
                     # the roofline that binds the STEP: vector-ALU issue time of all its kernels / the step time
                     "step_valu_issue": round(step_valu / step_ms, 3) if step_valu is not None else None,
                     "step_valu_issue_ms": round(step_valu, 3) if step_valu is not None else None,

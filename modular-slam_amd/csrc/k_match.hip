@@ -178,9 +178,11 @@ constexpr float MM_KEY_UNIT = 32768.f;
 // hundred rows have been seen — the update is skipped and the ageing of the bests (+32 per tile) is owed as a wave-uniform
 // scalar.  Exact: a key that does not beat the runner-up cannot enter the top-2, and equal keys do not exist (the age
 // fields differ).  Costs 10 instructions per block where it does not fire, so small train sets (cfg2) run without it.
-template <int QT, bool SKIP = false>
+// PIPE (QT = 4, no SKIP: the batched cfg2 / cfg4 shape): the train-tile loop in the hand-scheduled form described at the loop.
+template <int QT, bool SKIP = false, bool PIPE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_match_knn2_fp4(MatchArgs a)
 {
+    static_assert(!PIPE || (QT == 4 && !SKIP), "the scheduled loop is written for four query tiles per wave without tile skipping");
     __shared__ __attribute__((aligned(16))) uint8_t tile[2][32 * MM_TROW];
     __shared__ uint32_t lut[256]; // byte -> its 8 bits as FP4 +1.0 (0x2) / -1.0 (0xA)
 
@@ -366,6 +368,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     for(int i = 0; i < 16; ++i)
         pend[i] = 0u; // "tile -1": keys below 2^15 never beat a real neighbour
     uint32_t d_next;
+    if constexpr(PIPE)
+    {
+    // ---- the scheduled loop (round 6) ---------------------------------------------------------------------------------
+    // A 32x32x64 FP4 MFMA keeps the SIMD's matrix core busy for 32 cycles but takes ONE issue slot; the 5-instruction top-2
+    // bundle of four keys takes 20 cycles of vector issue.  The compiler, left alone, emits the sixteen MFMAs of a train tile
+    // back to back (the wave then sits in front of the busy matrix core for 512 cycles) and the ~100 vector instructions of
+    // the four top-2 updates after them (the matrix core idles for 430): the two pipes alternate instead of overlapping, and
+    // the second wave of the SIMD, which started in phase, does the same at the same time — 957 cycles per tile and wave
+    // measured against 512 of matrix-core time.  Here the order is fixed by hand (a scheduling barrier after every slot):
+    // every slot is ONE MFMA plus ONE top-2 bundle of keys that were finished half a tile earlier —
+    //   slots 1-8  : MFMAs of query tiles 0, 1 on train tile t   |  top-2 of query tiles 2, 3 on train tile t - 1
+    //   slots 9-16 : MFMAs of query tiles 2, 3 on train tile t   |  top-2 of query tiles 0, 1 on train tile t
+    // so the vector work (<= 7 instructions = 28 cycles per slot) runs in the shadow of the matrix core.  The four
+    // accumulators are the key registers (no second set); a chain's dependent MFMA follows its producer by two slots.  The
+    // staging of tile t + 1 (table look-ups, LDS write, the global fetch of tile t + 2) rides in slots 1 - 5; the barrier
+    // stands after slot 10 and the fragments of tile t + 1 replace those of tile t as soon as their last MFMA has issued.
+    if(t_end > t_begin)
+    {
+        v16f acc0, acc1, acc2, acc3;
+#pragma unroll
+        for(int i = 0; i < 16; ++i)
+            acc0[i] = acc1[i] = acc2[i] = acc3[i] = 0.f; // "tile -1": keys below 2^15 never beat a real neighbour
+        stage(t_begin & 1, fetch(t_begin));
+        d_next = fetch(t_begin + 1);
+        __syncthreads();
+        v8i af[4];
+        read_frags(t_begin & 1, af);
+        const int n_full = t_end - 1; // the slice's last tile (the only one that can be partial) is peeled: its keys need masking
+#define MM_SLOT() __builtin_amdgcn_sched_barrier(0)
+#define MM_MFMA(ACC, U, S, C) ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[S], b[U][S], C, 4, 4, 0, 127, 0, 127 + 14)
+#define MM_AGE(U)                                                                                                      \
+    best0[U] = __float_as_uint(__uint_as_float(best0[U]) + 32.f);                                                      \
+    best1[U] = __float_as_uint(__uint_as_float(best1[U]) + 32.f)
+#define MM_BUNDLE(ACC, U, I)                                                                                           \
+    {                                                                                                                  \
+        const uint32_t m01 = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(best0[U]), ACC[I], ACC[I + 1]));  \
+        best0[U] = max(max(best0[U], __float_as_uint(ACC[I])), __float_as_uint(ACC[I + 1]));                           \
+        const uint32_t m23 = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(best0[U]), ACC[I + 2], ACC[I + 3])); \
+        best0[U] = max(max(best0[U], __float_as_uint(ACC[I + 2])), __float_as_uint(ACC[I + 3]));                       \
+        best1[U] = max(max(best1[U], m01), m23);                                                                       \
+        asm volatile("" : "+v"(best1[U])); /* (keeps the runner-up's max3 in this slot: it would be sunk to the loop's end) */ \
+    }
+#define MM_FRAG(BUF, S)                                                                                                \
+    {                                                                                                                  \
+        const uint4 e = *reinterpret_cast<const uint4*>(&tile[BUF][r * MM_TROW + (2 * S + h) * 16]);                   \
+        af[S] = v8i{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};                                               \
+    }
+#pragma unroll 1
+        for(int t = t_begin; t < n_full; ++t)
+        {
+            const int nb = (t & 1) ^ 1;
+            // slots 1 - 8
+            MM_AGE(2);
+            MM_BUNDLE(acc2, 2, 0);
+            const uint4 ex = expand(d_next); // tile t + 1: the four table look-ups
+            MM_SLOT();
+            MM_MFMA(acc0, 0, 0, cinit);
+            MM_SLOT();
+            MM_BUNDLE(acc2, 2, 4);
+            MM_SLOT();
+            MM_MFMA(acc1, 1, 0, cinit);
+            MM_SLOT();
+            MM_BUNDLE(acc2, 2, 8);
+            *reinterpret_cast<uint4*>(&tile[nb][tr * MM_TROW + tw * 16]) = ex;
+            MM_SLOT();
+            MM_MFMA(acc0, 0, 1, acc0);
+            MM_SLOT();
+            MM_BUNDLE(acc2, 2, 12);
+            MM_SLOT();
+            MM_MFMA(acc1, 1, 1, acc1);
+            MM_SLOT();
+            MM_AGE(3);
+            MM_BUNDLE(acc3, 3, 0);
+            d_next = fetch(t + 2);
+            MM_SLOT();
+            MM_MFMA(acc0, 0, 2, acc0);
+            MM_SLOT();
+            MM_BUNDLE(acc3, 3, 4);
+            MM_SLOT();
+            MM_MFMA(acc1, 1, 2, acc1);
+            MM_SLOT();
+            MM_BUNDLE(acc3, 3, 8);
+            MM_SLOT();
+            MM_MFMA(acc0, 0, 3, acc0);
+            MM_SLOT();
+            MM_BUNDLE(acc3, 3, 12);
+            MM_SLOT();
+            MM_MFMA(acc1, 1, 3, acc1);
+            MM_SLOT();
+            // slots 9 - 16
+            MM_AGE(0);
+            MM_BUNDLE(acc0, 0, 0);
+            MM_SLOT();
+            MM_MFMA(acc2, 2, 0, cinit);
+            MM_SLOT();
+            MM_BUNDLE(acc0, 0, 4);
+            MM_SLOT();
+            MM_MFMA(acc3, 3, 0, cinit);
+            MM_SLOT();
+            __syncthreads(); // tile t + 1 is staged; every wave has issued its last read of the fragments' first quarter
+            MM_FRAG(nb, 0);
+            MM_BUNDLE(acc0, 0, 8);
+            MM_SLOT();
+            MM_MFMA(acc2, 2, 1, acc2);
+            MM_SLOT();
+            MM_BUNDLE(acc0, 0, 12);
+            MM_SLOT();
+            MM_MFMA(acc3, 3, 1, acc3);
+            MM_SLOT();
+            MM_FRAG(nb, 1);
+            MM_AGE(1);
+            MM_BUNDLE(acc1, 1, 0);
+            MM_SLOT();
+            MM_MFMA(acc2, 2, 2, acc2);
+            MM_SLOT();
+            MM_BUNDLE(acc1, 1, 4);
+            MM_SLOT();
+            MM_MFMA(acc3, 3, 2, acc3);
+            MM_SLOT();
+            MM_FRAG(nb, 2);
+            MM_BUNDLE(acc1, 1, 8);
+            MM_SLOT();
+            MM_MFMA(acc2, 2, 3, acc2);
+            MM_SLOT();
+            MM_BUNDLE(acc1, 1, 12);
+            MM_SLOT();
+            MM_MFMA(acc3, 3, 3, acc3);
+            MM_SLOT();
+            MM_FRAG(nb, 3);
+            MM_SLOT();
+        }
+        if(n_full > t_begin)
+        {
+            // query tiles 2, 3 of the last full tile
+            MM_AGE(2);
+            MM_BUNDLE(acc2, 2, 0);
+            MM_BUNDLE(acc2, 2, 4);
+            MM_BUNDLE(acc2, 2, 8);
+            MM_BUNDLE(acc2, 2, 12);
+            MM_AGE(3);
+            MM_BUNDLE(acc3, 3, 0);
+            MM_BUNDLE(acc3, 3, 4);
+            MM_BUNDLE(acc3, 3, 8);
+            MM_BUNDLE(acc3, 3, 12);
+        }
+#undef MM_SLOT
+#undef MM_MFMA
+#undef MM_AGE
+#undef MM_BUNDLE
+#undef MM_FRAG
+        {
+            // the peeled last tile (its fragments are in af): keys of rows past the end are masked
+            const int base = n_full * 32;
+#pragma unroll
+            for(int u = 0; u < QT; ++u)
+            {
+                dots(af, u, keyA);
+#pragma unroll
+                for(int i = 0; i < 16; ++i)
+                    if(base + (i & 3) + 8 * (i >> 2) + 4 * h >= n_from)
+                        keyA[i] = 0u;
+                top2(keyA, best0[u], best1[u], owed[u]);
+            }
+        }
+    }
+    }
+    else
     if(t_end > t_begin) // (an empty slice keeps "no neighbour": more slices than tiles)
     {
     stage(t_begin & 1, fetch(t_begin));
@@ -486,7 +655,7 @@ __global__ __launch_bounds__(256) void k_match_merge(MatchArgs a)
     a.dist1[o] = (k1 >> 15) ? (int32_t)(257u - (k1 >> 15)) : INT_MAX;
 }
 
-template <int QT, bool SKIP = false>
+template <int QT, bool SKIP = false, bool PIPE = false>
 static void launch_fp4(MatchArgs a, int n_pairs, hipStream_t s)
 {
     a.n_pairs = n_pairs;
@@ -494,14 +663,14 @@ static void launch_fp4(MatchArgs a, int n_pairs, hipStream_t s)
     const unsigned grid = (unsigned)((n_pairs + 7) / 8) * 8u * (unsigned)a.wg_per_pair;
     if(a.n_slices > 1 && a.partial)
     {
-        hipLaunchKernelGGL((k_match_knn2_fp4<QT, SKIP>), dim3(grid, a.n_slices), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_match_knn2_fp4<QT, SKIP, PIPE>), dim3(grid, a.n_slices), dim3(256), 0, s, a);
         // (merging inside k_ratio_compact instead of a launch of its own measured slower: 51.6 vs 49.4 us per call — that kernel
         // is one workgroup walking the queries in order)
         hipLaunchKernelGGL(k_match_merge, dim3((a.cap + 255) / 256, n_pairs), dim3(256), 0, s, a);
         return;
     }
     a.n_slices = 1;
-    hipLaunchKernelGGL((k_match_knn2_fp4<QT, SKIP>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_match_knn2_fp4<QT, SKIP, PIPE>), dim3(grid), dim3(256), 0, s, a);
 }
 
 int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
@@ -522,6 +691,8 @@ int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
             launch_fp4<2>(a, n_pairs, s);
         else if(max_train >= skip_from) // long scans (cfg5: 10 k train rows): most late blocks cannot change a top-2
             launch_fp4<4, true>(a, n_pairs, s);
+        else if([] { const char* e = getenv("MSLAM_HIP_MATCH_PIPE"); return !e || atoi(e) != 0; }()) // (per launch: A/B runs switch it)
+            launch_fp4<4, false, true>(a, n_pairs, s);
         else
             launch_fp4<4>(a, n_pairs, s);
         return 1;

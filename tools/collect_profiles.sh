@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/collect_profiles.sh r03_a'
 # Writes under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards:
 #   kt/kt_kernel_stats.csv -> profiles/<tag>_kernel_stats.csv, pmc_per_step.json -> profiles/<tag>_pmc_per_step.json and
-#   profiles/r05_pmc_per_step.json (the name bench.py reads), bench*.json -> profiles/<tag>_bench*.json
+#   profiles/r06_pmc_per_step.json (the name bench.py reads), bench*.json -> profiles/<tag>_bench*.json
 # Counters are collected in their own passes (no trace domains besides kernel dispatch data), as
 # MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass.  The program itself follows `--`.
 set -e
@@ -21,7 +21,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY 
 python tools/summarize_counters.py 3 "$OUT/pmc_per_step.json" "$OUT/fetch/f_counter_collection.csv" "$OUT/write/w_counter_collection.csv" "$OUT/sq/sq_counter_collection.csv" > "$OUT/pmc_per_step.txt"
 cat "$OUT/pmc_per_step.txt"
 # the bench line proper reads the summary from profiles/: put it there for this run
-cp "$OUT/pmc_per_step.json" profiles/r05_pmc_per_step.json
+cp "$OUT/pmc_per_step.json" profiles/r06_pmc_per_step.json
 timeout -k 10 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cp "$OUT/fetch/f_counter_collection.csv" "$OUT/pmc_fetch_counter_collection.csv"
 cp "$OUT/write/w_counter_collection.csv" "$OUT/pmc_write_counter_collection.csv"

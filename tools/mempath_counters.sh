@@ -18,7 +18,9 @@ for G in "TCC_HIT_sum TCC_MISS_sum" \
          "TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
          "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
          "TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-         "TA_BUFFER_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum"; do
+         "TA_BUFFER_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum" \
+         "TA_TA_BUSY_sum GRBM_GUI_ACTIVE" \
+         "SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 120 rocprofv3 --pmc $G --output-format csv -d "$OUT/p$i" -o g -- python3 tools/stage_times.py --reps 2 > "$OUT/p$i.out" 2> "$OUT/p$i.err"
   rc=$?
