@@ -687,12 +687,16 @@ int launch_match_knn2(const MatchArgs& a, int n_pairs, hipStream_t s)
         // a handful of pairs (the synchronous single-frame calls): two query tiles per wave, twice as many waves —
         // the kernel's latency is what counts there (39 -> 13 us for one 1900 x 1900 pair), not its throughput
         const int skip_from = [] { const char* e = getenv("MSLAM_HIP_MATCH_SKIP_FROM"); return e ? atoi(e) : 6000; }(); // (read per launch: a test switches it)
+        // MSLAM_HIP_MATCH_PIPE=0 (read per launch: A/B runs and a test switch it) selects the round-5 loops: the compiler-
+        // scheduled one, and from `skip_from` train rows on the tile-skipping one (cfg5: 0.64 ms per 64 x 10058^2 pairs; the
+        // scheduled loop does the same work in 0.57 ms without skipping anything, so it takes every size by default)
+        const bool pipe = [] { const char* e = getenv("MSLAM_HIP_MATCH_PIPE"); return !e || atoi(e) != 0; }();
         if(n_pairs <= 4)
             launch_fp4<2>(a, n_pairs, s);
+        else if(pipe)
+            launch_fp4<4, false, true>(a, n_pairs, s);
         else if(max_train >= skip_from) // long scans (cfg5: 10 k train rows): most late blocks cannot change a top-2
             launch_fp4<4, true>(a, n_pairs, s);
-        else if([] { const char* e = getenv("MSLAM_HIP_MATCH_PIPE"); return !e || atoi(e) != 0; }()) // (per launch: A/B runs switch it)
-            launch_fp4<4, false, true>(a, n_pairs, s);
         else
             launch_fp4<4>(a, n_pairs, s);
         return 1;

@@ -242,13 +242,16 @@ def test_batch_device_path(pkg, orc, synth_frames, matcher):
     c.close()
 
 
-@pytest.mark.parametrize("kcap,skip_env", [(8192, None), (4096, "0")])
-def test_batch_matcher_tile_skip_path(pkg, orc, synth_frames, monkeypatch, kcap, skip_env):
-    """k_match_knn2_fp4<4, SKIP = true> — more than four pairs and a train capacity of at least MSLAM_HIP_MATCH_SKIP_FROM
-    (6000) rows: a (train tile, query tile) block that cannot change any lane's top-2 skips its update, the owed ageing of the
-    keys is applied later.  Dense keypoint sets (min-area 60: ~4 k per frame, 125 train tiles per query) through the
-    batched path, against the oracle's matcher; the second case forces the skip path onto the K = 4096 batch shape."""
+@pytest.mark.parametrize("kcap,skip_env,pipe", [(8192, None, "0"), (4096, "0", "0"), (8192, None, "1"), (4096, None, "0")])
+def test_batch_matcher_tile_skip_path(pkg, orc, synth_frames, monkeypatch, kcap, skip_env, pipe):
+    """the batched matrix-core loops on long train sets.  pipe = "1" (the default): the hand-scheduled loop
+    k_match_knn2_fp4<4, false, true> takes every size.  pipe = "0" (MSLAM_HIP_MATCH_PIPE=0, the round-5 loops):
+    k_match_knn2_fp4<4, SKIP = true> from MSLAM_HIP_MATCH_SKIP_FROM (6000) train rows on — a (train tile, query tile) block
+    that cannot change any lane's top-2 skips its update, the owed ageing of the keys is applied later — and the compiler-
+    scheduled loop below.  Dense keypoint sets (min-area 60: ~4 k per frame, 125 train tiles per query) through the batched
+    path, against the oracle's matcher; skip_env = "0" forces the skip path onto the K = 4096 batch shape."""
     import torch
+    monkeypatch.setenv("MSLAM_HIP_MATCH_PIPE", pipe)
     if skip_env is not None:
         monkeypatch.setenv("MSLAM_HIP_MATCH_SKIP_FROM", skip_env)
     area = 60 if kcap == 8192 else 1000
