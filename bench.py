@@ -48,7 +48,7 @@ STAGE_KERNEL = {"levels": "void mslam::k_level_chain<false, 8, true, W, C> (gray
                 "pnp_gather": "mslam::k_pnp_gather", "pnp_ransac": "mslam::k_pnp_ransac_batch", "gray": "void mslam::k_gray_blur<true, 0>",
                 "resize": "void mslam::k_resize_blur<false, N, true, 0> (one launch per level)", "fast": "mslam::k_fast_cells",
                 "quadtree": "mslam::k_quadtree", "blur": "mslam::k_blur2", "describe": "void mslam::k_describe<true>",
-                "match_knn2": "void mslam::k_match_knn2_fp4<4>", "ratio_compact": "mslam::k_ratio_compact",
+                "match_knn2": "void mslam::k_match_knn2_fp4<4, false, true>", "ratio_compact": "mslam::k_ratio_compact",
                 "backproject": "mslam::k_backproject"}
 POPCOUNT_KERNEL = "void mslam::k_match_knn2<8, 1, 8>"
 # kernel name (rocprofv3, without the argument list) -> stage of the step; a stage can be several kernels / launches

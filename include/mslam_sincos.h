@@ -1,9 +1,14 @@
 /* mslam_sincos.h — the cos/sin used by the cv::ORB detector mode (orb_feature.cpp:25,40; OpenCV orb.cpp
  * computeOrbDescriptors: `angle *= (float)(CV_PI/180.f); float a = (float)cos(angle), b = (float)sin(angle);`).
  *
- * Inside namespace cv the unqualified cos(angle) of a float resolves, in a GCC / libstdc++ build, to the C library's DOUBLE
- * function (the float overloads of <cmath> live in namespace std; cv's using-list does not take them) — the (float) casts in
- * the source say the same: the reference computes (float)cos((double)angle).  A GPU cannot call the host library, so this
+ * WORKING HYPOTHESIS (unpinned: no OpenCV build exists in this image; tests/test_opencv_pin.py skips as PARITY UNPINNED until
+ * an opencv_dump golden file is installed): inside namespace cv the unqualified cos(angle) of a float resolves, in a GCC /
+ * libstdc++ build, to the C library's DOUBLE function (the float overloads of <cmath> live in namespace std; cv's using-list
+ * does not take them) — the (float) casts in the source point the same way — i.e. the reference computes
+ * (float)cos((double)angle).  The argument is fragile: libstdc++'s <math.h> wrapper does `using std::cos;`, so if any header of
+ * the orb.cpp translation unit includes <math.h> instead of <cmath>, cos(float) is the FLOAT overload = cosf, which differs in
+ * the last bit for 0.14 % of the arguments (below).  Until the pin exists this stays a DOCUMENTED POSSIBLE DEVIATION of the
+ * cv::ORB mode; oracle/opencv_check/compare.py tolerates it with a bound and counts it.  A GPU cannot call the host library, so this
  * routine evaluates cos / sin of the float angle in IEEE double arithmetic (Cody-Waite reduction to [-pi/4, pi/4], Taylor
  * polynomials to r^16 / r^15: absolute error < 1e-15 for |x| <= 8) and rounds the result to float.  Every operation is a
  * single rounded double add / multiply / floor in a fixed order, so the host build (gcc -ffp-contract=off) and the device

@@ -766,6 +766,16 @@ static int create_impl(mslam_hip_ctx* c)
     {
         const char* e = getenv("MSLAM_HIP_OVERLAP_MATCH");
         c->overlap_match = !(e && atoi(e) == 0);
+        // knobs of the synchronous single-frame calls: read per context, at creation (a test or a tool that sets them before
+        // creating its context gets what it asked for)
+        auto on = [](const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; };
+        c->knob_mirror_results = on("MSLAM_HIP_MIRROR_RESULTS");
+        c->knob_zero_copy = on("MSLAM_HIP_ZERO_COPY_FRAME");
+        c->knob_match_graph = on("MSLAM_HIP_MATCH_GRAPH");
+        const char* zm = getenv("MSLAM_HIP_ZERO_COPY_MAX_BYTES");
+        // measured (round 6, tools/latency.py, detect median in us, zero-copy / copy): 640x480 146 / 162, 1280x720 374 / 302,
+        // 1920x1080 818 / 620 — the kernel's PCIe reads (39 GB/s) beat the DMA's fixed cost only for small frames
+        c->zero_copy_max_bytes = zm ? (size_t)atoll(zm) : (size_t)1200000;
         const char* m = getenv("MSLAM_HIP_MATCHER");
         c->matcher_kind = (m && std::strcmp(m, "popcount") == 0) ? MSLAM_HIP_MATCHER_POPCOUNT : MSLAM_HIP_MATCHER_AUTO;
     }
@@ -1256,7 +1266,7 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     uint8_t* h_ang = h_oct + K * 4;
     uint8_t* h_resp = h_ang + K * 4;
     // (MSLAM_HIP_MIRROR_RESULTS=0: the packing kernel of round 3 instead of k_describe's own stores into the mapped block)
-    static const bool mirror_env = [] { const char* e = getenv("MSLAM_HIP_MIRROR_RESULTS"); return !e || atoi(e) != 0; }();
+    const bool mirror_env = c->knob_mirror_results; // (read at context creation)
     struct MirrorScope
     {
         mslam_hip_ctx* c;
@@ -1280,7 +1290,9 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
     // (its deep-prefetch instance has every row of a block in flight at once: one round trip per block).  A copy from the
     // caller's pageable buffer blocks the host for the same CPU copy into the runtime's own staging area and only then starts
     // a DMA of ~20 us in front of the first kernel: detect 164 -> 148 us.  MSLAM_HIP_ZERO_COPY_FRAME=0: the copy.
-    static const bool zero_copy = [] { const char* e = getenv("MSLAM_HIP_ZERO_COPY_FRAME"); return !e || atoi(e) != 0; }();
+    // The knob is read at context creation; frames above zero_copy_max_bytes (1.2 MB, MSLAM_HIP_ZERO_COPY_MAX_BYTES) take the
+    // copy: at 1280x720 and 1920x1080 the kernel's PCIe reads lose to the DMA (numbers at the knob, create_impl).
+    const bool zero_copy = c->knob_zero_copy && (size_t)width * height * 3 <= c->zero_copy_max_bytes;
     const uint8_t* frame_src = c->d_stage;
     if(zero_copy)
     {
@@ -1307,11 +1319,16 @@ int mslam_hip_detect(mslam_hip_ctx* c, const uint8_t* bgr, int width, int height
             if(!rc)
                 rc = enqueue_results();
             const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+            // the captured graph is destroyed on every way out
+            const hipError_t e_inst = (!rc && e == hipSuccess) ? hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) : hipSuccess;
+            if(graph)
+                (void)hipGraphDestroy(graph);
+            if(e_inst != hipSuccess)
+                exec = nullptr;
             if(rc)
                 return rc;
             HIPCHK(c, e);
-            HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
+            HIPCHK(c, e_inst);
         }
         HIPCHK(c, hipGraphLaunch(exec, c->stream));
     }
@@ -1519,8 +1536,10 @@ static int host_match_graph(mslam_hip_ctx* c, const uint8_t* from_desc, int n_fr
 {
     const size_t fcap = (size_t)c->hm_from_cap, tcap = (size_t)c->hm_to_cap;
     uint8_t* h_cnt = c->h_hm + (fcap + tcap) * 32;
-    std::memcpy(c->h_hm, from_desc, (size_t)n_from * 32);
-    std::memcpy(c->h_hm + fcap * 32, to_desc, (size_t)n_to * 32);
+    if(n_from > 0)
+        std::memcpy(c->h_hm, from_desc, (size_t)n_from * 32);
+    if(n_to > 0)
+        std::memcpy(c->h_hm + fcap * 32, to_desc, (size_t)n_to * 32);
     const int32_t counts[4] = {n_from, n_to, 0, 0};
     std::memcpy(h_cnt, counts, sizeof(counts));
     int32_t* res_dev = reinterpret_cast<int32_t*>(c->d_h_hm + (fcap + tcap) * 32 + 16);
@@ -1567,11 +1586,20 @@ static int host_match_graph(mslam_hip_ctx* c, const uint8_t* from_desc, int n_fr
             c->last_match_kernel = launch_match_knn2(m, 1, c->stream);
             launch_ratio_compact(r, 1, c->stream);
         }
+        const hipError_t e_launch = hipGetLastError(); // a launch made inside the capture that was rejected
         const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+        // the captured graph is destroyed on EVERY way out of here, instantiated or not
+        hipError_t e3 = (e == hipSuccess && e_launch == hipSuccess && e2 == hipSuccess)
+                            ? hipGraphInstantiate(&c->match_graph, graph, nullptr, nullptr, 0)
+                            : hipSuccess;
+        if(graph)
+            (void)hipGraphDestroy(graph);
+        if(e3 != hipSuccess)
+            c->match_graph = nullptr;
         HIPCHK(c, e);
+        HIPCHK(c, e_launch);
         HIPCHK(c, e2);
-        HIPCHK(c, hipGraphInstantiate(&c->match_graph, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
+        HIPCHK(c, e3);
         c->match_graph_from_cap = c->hm_from_cap;
         c->match_graph_to_cap = c->hm_to_cap;
         c->match_graph_kind = c->matcher_kind;
@@ -1581,6 +1609,8 @@ static int host_match_graph(mslam_hip_ctx* c, const uint8_t* from_desc, int n_fr
     HIPCHK(c, hipGraphLaunch(c->match_graph, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int32_t n = res[2 * tcap];
+    if(n < 0 || n > n_to || (size_t)n > tcap) // (a count from mapped memory sizes the copies below: never trust it blindly)
+        return fail(c, MSLAM_HIP_E_RUNTIME, "match: the kernel reported an impossible match count");
     std::memcpy(from_idx, res, (size_t)n * 4);
     std::memcpy(to_idx, res + tcap, (size_t)n * 4);
     *n_out = n;
@@ -1670,7 +1700,7 @@ int mslam_hip_match(mslam_hip_ctx* c, const uint8_t* from_desc, int n_from, cons
         return rc;
     // the captured form: when the staging capacities are at most twice what this call needs (the upload always moves whole
     // capacities) and the matrix-core kernel's train range holds them
-    static const bool graph_env = [] { const char* e = getenv("MSLAM_HIP_MATCH_GRAPH"); return !e || atoi(e) != 0; }();
+    const bool graph_env = c->knob_match_graph; // (read at context creation)
     if(graph_env && c->use_graph && !c->profiling && !c->inplace_timing && c->hm_from_cap >= n_from && c->hm_to_cap >= n_to &&
        c->hm_from_cap + c->hm_to_cap <= 2 * (n_from + n_to) + 2048 && c->hm_from_cap <= 32736)
         return host_match_graph(c, from_desc, n_from, to_desc, n_to, n_out, from_idx, to_idx);

@@ -94,6 +94,8 @@ struct mslam_hip_ctx
     int blur_wpf = 0;
     int fused_levels = 0;  // levels 0 .. fused_levels-1 are produced and blurred by k_level.hip; k_blur2 takes the rest
     int level_k6 = 9;      // k_level.hip: rows per block = 6 k6 + 2
+    bool knob_mirror_results = true, knob_zero_copy = true, knob_match_graph = true; // MSLAM_HIP_MIRROR_RESULTS / _ZERO_COPY_FRAME / _MATCH_GRAPH at creation
+    size_t zero_copy_max_bytes = 1200000; // frames above this size are copied by DMA instead of read over PCIe by the gray kernel
     int level_chain = 0, level_chain_frames = 2, level_chain_waves = 8, level_chain_k6 = 9; // k_level_chain (k_level.hip)
     int level_k6_small = 1; // the same for batches of fewer than 8 frames (latency: one wave's walk is the launch's duration)
     uint32_t* d_cell_cnt = nullptr;

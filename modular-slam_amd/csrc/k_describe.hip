@@ -191,7 +191,12 @@ __global__ __launch_bounds__(256) void k_describe(Geometry g, DescArgs a, int bp
         a.count[frame] = min(total, a.max_kp);
         if(total > a.max_kp)
             atomicOr(a.flags, kFlagKpOverflow);
-        if(a.h_mirror) // (one frame per launch; the flags of the earlier kernels of the call are final by now)
+        // Mirror mode (the synchronous single-frame call): the host reads count and flags ONLY from the mapped block, so this
+        // snapshot must see every flag of the call.  It does because k_describe is the LAST kernel of the single-frame sequence
+        // (api.hip: enqueue_detect, both detector modes) and this thread is its only flag writer: the flags of the earlier
+        // kernels are final when it starts.  A kernel appended behind k_describe, or a second flag writer inside it, must send
+        // the flags by a copy of its own instead (tests/test_gpu_parity.py::test_capacity_is_loud runs both result paths).
+        if(a.h_mirror)
         {
             reinterpret_cast<int32_t*>(a.h_mirror)[0] = min(total, a.max_kp);
             reinterpret_cast<uint32_t*>(a.h_mirror)[1] = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (total > a.max_kp ? kFlagKpOverflow : 0u);

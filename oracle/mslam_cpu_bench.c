@@ -72,6 +72,10 @@ static void* bench_thread(void* arg)
     }
     const size_t fb = (size_t)j->W * j->H * 3;
     j->rc = 0;
+    /* an allocation that failed: the thread still goes through the gate (the caller counts it) but runs no frame and reports -3 */
+    const int alloc_ok = octave && angle && resp && fi && ti && xy[0] && xy[1] && desc[0] && desc[1];
+    if(!alloc_ok)
+        j->rc = -3;
     pthread_mutex_lock(&j->gate->mu);
     ++j->gate->ready;
     pthread_cond_broadcast(&j->gate->cv);
@@ -80,7 +84,7 @@ static void* bench_thread(void* arg)
     const int go = j->gate->go;
     pthread_mutex_unlock(&j->gate->mu);
     const double t0 = now_s();
-    for(int i = 0; go > 0 && i < j->count; ++i)
+    for(int i = 0; go > 0 && alloc_ok && i < j->count; ++i)
     {
         const int cur = i & 1, prev = cur ^ 1;
         const uint8_t* f = j->frames + (size_t)((j->first + i) % j->n_unique) * fb;
@@ -119,18 +123,31 @@ static void* bench_thread(void* arg)
 int mso_bench_stream(const uint8_t* frames, int n_unique, int W, int H, const mso_orb_params* p,
                      const mso_cvorb_params* cvp, int n_threads, int frames_per_thread, int max_kp, double out[5])
 {
-    static int tuned = 0;
-    if(!tuned)
-    {
-        mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024); /* glibc's upper limit for this knob */
-        mallopt(M_TRIM_THRESHOLD, 1 << 30);
-        mallopt(M_ARENA_MAX, 4096);
-        tuned = 1;
-    }
     if(n_threads < 1 || frames_per_thread < 1 || n_unique < 1)
         return -2;
+    /* process-wide allocator settings, for the duration of this call only (the caller is a Python process that goes on to do
+     * other things): raised here, put back to glibc's documented defaults before returning (128 KB thresholds, arena limit
+     * chosen by the library).  What cannot be restored is glibc's DYNAMIC adjustment of the mmap threshold, which any explicit
+     * setting switches off for the rest of the process: a footnote for a test / bench process, stated here. */
+    mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024); /* glibc's upper limit for this knob */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_ARENA_MAX, 4096);
+#define MSO_RESTORE_MALLOPT()                                                                                          \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        mallopt(M_MMAP_THRESHOLD, 128 * 1024);                                                                         \
+        mallopt(M_TRIM_THRESHOLD, 128 * 1024);                                                                         \
+        mallopt(M_ARENA_MAX, 0);                                                                                       \
+    } while(0)
     mso_bench_job* jobs = (mso_bench_job*)calloc((size_t)n_threads, sizeof(mso_bench_job));
     pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    if(!jobs || !th)
+    {
+        free(jobs);
+        free(th);
+        MSO_RESTORE_MALLOPT();
+        return -2;
+    }
     mso_bench_gate gate;
     pthread_mutex_init(&gate.mu, NULL);
     pthread_cond_init(&gate.cv, NULL);
@@ -171,6 +188,7 @@ int mso_bench_stream(const uint8_t* frames, int n_unique, int W, int H, const ms
         pthread_mutex_destroy(&gate.mu);
         free(jobs);
         free(th);
+        MSO_RESTORE_MALLOPT();
         return -2;
     }
     for(int t = 0; t < n_threads; ++t)
@@ -186,7 +204,9 @@ int mso_bench_stream(const uint8_t* frames, int n_unique, int W, int H, const ms
             smin = jobs[t].seconds;
         if(jobs[t].seconds > smax)
             smax = jobs[t].seconds;
-        if(jobs[t].rc != 0)
+        if(jobs[t].rc == -3)
+            rc = -2; /* a thread could not allocate its buffers */
+        else if(jobs[t].rc != 0 && rc == 0)
             rc = -1;
     }
     out[0] = kp;
@@ -198,5 +218,7 @@ int mso_bench_stream(const uint8_t* frames, int n_unique, int W, int H, const ms
     pthread_mutex_destroy(&gate.mu);
     free(jobs);
     free(th);
+    MSO_RESTORE_MALLOPT();
+#undef MSO_RESTORE_MALLOPT
     return rc;
 }

@@ -137,11 +137,28 @@ def test_quadtree_storage_forms(pkg, orc):
     assert seen >= {"big", "big-overflow", "global"}, seen
 
 
-def test_capacity_is_loud(pkg, synth_frames):
+@pytest.mark.parametrize("mirror", ["1", "0"])
+def test_capacity_is_loud(pkg, orc, synth_frames, monkeypatch, mirror):
+    """an overflow must reach the caller in BOTH result paths of the synchronous call: k_describe mirroring count + flags into
+    the mapped result block itself (the default — block 0 / thread 0 writes a snapshot of the flags when it starts; it is the
+    last flag writer of the single-frame sequence, csrc/k_describe.hip) and the round-3 packing kernel
+    (MSLAM_HIP_MIRROR_RESULTS=0, read at context creation).  Keypoint capacity, candidate capacity, and a clean call after
+    each failure on the same context."""
+    monkeypatch.setenv("MSLAM_HIP_MIRROR_RESULTS", mirror)
     c = pkg.Context(width=640, height=480, max_keypoints=100)
+    for _ in range(2):   # the flags are cleared by the failing call: the second one fails for its own overflow
+        with pytest.raises(pkg.MslamHipError) as e:
+            c.detect(synth_frames[0])
+        assert e.value.code == pkg.E_CAPACITY
+    c.close()
+    c = pkg.Context(width=640, height=480, max_candidates=256)          # FAST candidate lists overflow (an earlier kernel's flag)
     with pytest.raises(pkg.MslamHipError) as e:
         c.detect(synth_frames[0])
     assert e.value.code == pkg.E_CAPACITY
+    c.close()
+    c = pkg.Context(width=640, height=480)
+    got, ref = c.detect(synth_frames[0]), orc.detect(synth_frames[0], orc.params())
+    assert len(got["xy"]) == len(ref["xy"]) and np.array_equal(got["desc"], ref["desc"])
     c.close()
 
 

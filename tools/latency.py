@@ -35,7 +35,8 @@ def main():
         keep = [torch.from_numpy(f.copy()).pin_memory() for f in frames]
         frames = [k.numpy() for k in keep]
     cv = a.detector == "cvorb"
-    c = pkg.Context(width=a.width, height=a.height, max_batch=1,
+    area = max(1, -(-a.width * a.height // (640 * 480)))    # capacities scale with the frame area, as in bench.py
+    c = pkg.Context(width=a.width, height=a.height, max_batch=1, max_keypoints=min(32736, 4096 * area), max_candidates=16384 * area,
                     detector=pkg.DETECTOR_CV_ORB if cv else pkg.DETECTOR_DISTRIBUTED)
     L, K = c.L, c.params.max_keypoints
     xy = np.empty((K, 2), np.float32)
