@@ -154,16 +154,18 @@ static void launch_variant(MatchArgs a, int n_pairs, hipStream_t s)
 
 // ---------------------------------------------------------------------------------------------------
 // Matrix-core form of the same search.  With every descriptor bit b expanded to the FP4 (E2M1) value 2b-1,
-// the dot product of two descriptors is 256 - 2*hamming, and v_mfma_scale_f32_32x32x64_f8f6f4 computes it
-// exactly (products +-1, f32 accumulation of integers below 2^24): a 32x32 tile of distances is 4 MFMAs
-// instead of 32*32*16 xor/popcount lane-operations.  The block scale of the query operand is 2^14 (the dot
-// product is even, so dot * 2^14 = (dot / 2) * 2^15), and the accumulator starts at 129 * 2^15 + (31 - row),
-// so what the matrix core delivers IS the sort key
-//   key(query, train j) = (dot / 2 + 129) * 2^15 + age,   age = 32 * (tiles scanned after j's tile) + 31 - (j & 31)
-// (larger key = smaller distance, then smaller train index: batchDistance's insertion order) and the VALU
-// only does the running top-2: one v_med3 + one v_max per pair, on the f32 bit patterns (positive floats
-// order like unsigned integers).  Keys below 2^15 mean "no neighbour".  The age field limits this kernel
-// to 32736 train rows; larger sets take the VALU kernel above.
+// the dot product of two descriptors is 256 - 2*hamming, and v_mfma_f32_32x32x64_f8f6f4 computes it
+// exactly (products +-1, f32 accumulation): a 32x32 tile of distances is 4 MFMAs instead of 32*32*16 xor/popcount
+// lane-operations.  The accumulator starts at 258 + (31 - row) * 2^-14, so what the matrix core delivers IS the sort key
+//   key(query, train j) = (dot + 258) + age * 2^-14,   age = 32 * (tiles scanned after j's tile) + 31 - (j & 31)
+// — below 2^10 with 14 fraction bits: 24 significant bits, every partial sum exact in f32 — larger key = smaller distance,
+// then smaller train index (batchDistance's insertion order), and the VALU only does the running top-2 on the f32 bit
+// patterns (positive floats order like unsigned integers).  Keys below 2 mean "no neighbour" (1023 tiles of ageing stay
+// below it).  key * 2^14 is the integer (dot / 2 + 129) << 15 | age (the dot product is even).  The age field limits this
+// kernel to 32736 train rows; larger sets take the VALU kernel above.
+// (Rounds 2-5 put the 2^14 into the instruction's block scale — v_mfma_scale_..., key = (dot / 2 + 129) * 2^15 + age.  The
+// scaled form is two issue slots, v_mfma_ld_scale + the MFMA; with both scale operands the constant 0 the compiler selects
+// the unscaled instruction, and the fraction bits carry the age instead.)
 // Queries are the B operand: the accumulator then has ONE query per lane column and 16 train rows in the
 // lane's 16 registers, so a query's top-2 stays in its lane (two lanes per query, merged at the end).
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -171,7 +173,13 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MM_TROW = 144;          // bytes of one expanded train row in LDS: 128 + 16 (conflict-free fragment reads)
 constexpr int MM_MAX_TRAIN = 32736;   // 32 * 1023: the age field is 15 bits (keys stay below 2^24: exact in f32)
-constexpr float MM_KEY_UNIT = 32768.f;
+constexpr float MM_AGE_UNIT = 1.f / 16384.f;   // one unit of the key's age field (2^-14: the key is (dot + 258) + age * 2^-14)
+constexpr float MM_TILE_AGE = 32.f * MM_AGE_UNIT; // what a key ages per train tile scanned after its own
+__device__ __forceinline__ uint32_t mm_key_int(uint32_t key_bits)
+{
+    // the key as the integer (dot / 2 + 129) << 15 | age: an exact power-of-two multiply of a value below 2^10 with 14 fraction bits
+    return (uint32_t)(__uint_as_float(key_bits) * 16384.f);
+}
 
 // SKIP (large train sets): before the 34-instruction top-2 update of a (train tile, query tile) block the wave checks whether
 // ANY of its keys beats the lane's current runner-up (8 v_max3 + a compare); if none does — the common case once a few
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
     for(int i = 0; i < 16; ++i)
     {
-        cinit[i] = 129.f * MM_KEY_UNIT + (float)(31 - ((i & 3) + 8 * (i >> 2) + 4 * h));
+        cinit[i] = 258.f + (float)(31 - ((i & 3) + 8 * (i >> 2) + 4 * h)) * MM_AGE_UNIT;
         zero[i] = 0u;
     }
     uint32_t best0[QT], best1[QT];
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         v16f acc = cinit;
 #pragma unroll
         for(int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[s], b[u][s], acc, 4, 4, 0, 127, 0, 127 + 14);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[s], b[u][s], acc, 4, 4, 0, 0, 0, 0);
 #pragma unroll
         for(int i = 0; i < 16; ++i)
             key[i] = __float_as_uint(acc[i]);
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             for(int i = 3; i < 15; i += 2)
                 mx = max(max(mx, key[i]), key[i + 1]);
             mx = max(mx, key[15]);
-            const float age = lag + 32.f; // what the bests have aged by the time these keys compete
+            const float age = lag + MM_TILE_AGE; // what the bests have aged by the time these keys compete
             // keys are positive floats holding integers: they order like their bit patterns
             if(__ballot(mx > __float_as_uint(__uint_as_float(b1) + age)) == 0ull)
             {
@@ -339,8 +347,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
         else
         {
-        b0 = __float_as_uint(__uint_as_float(b0) + 32.f); // everything found so far is one tile older
-        b1 = __float_as_uint(__uint_as_float(b1) + 32.f);
+        b0 = __float_as_uint(__uint_as_float(b0) + MM_TILE_AGE); // everything found so far is one tile older
+        b1 = __float_as_uint(__uint_as_float(b1) + MM_TILE_AGE);
         }
         // Running top-2 in bundles of four keys, 5 instructions per bundle instead of 8 (round 5: this update, not the matrix
         // pipe, is what the kernel waits for).  With b0 >= b1 and two new keys x, y: the best of {b0, b1, x, y} is
@@ -397,10 +405,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         read_frags(t_begin & 1, af);
         const int n_full = t_end - 1; // the slice's last tile (the only one that can be partial) is peeled: its keys need masking
 #define MM_SLOT() __builtin_amdgcn_sched_barrier(0)
-#define MM_MFMA(ACC, U, S, C) ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[S], b[U][S], C, 4, 4, 0, 127, 0, 127 + 14)
+#define MM_MFMA(ACC, U, S, C) ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[S], b[U][S], C, 4, 4, 0, 0, 0, 0)
 #define MM_AGE(U)                                                                                                      \
-    best0[U] = __float_as_uint(__uint_as_float(best0[U]) + 32.f);                                                      \
-    best1[U] = __float_as_uint(__uint_as_float(best1[U]) + 32.f)
+    best0[U] = __float_as_uint(__uint_as_float(best0[U]) + MM_TILE_AGE);                                                      \
+    best1[U] = __float_as_uint(__uint_as_float(best1[U]) + MM_TILE_AGE)
 #define MM_BUNDLE(ACC, U, I)                                                                                           \
     {                                                                                                                  \
         const uint32_t m01 = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(best0[U]), ACC[I], ACC[I + 1]));  \
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
             {
                 // age counted from the end of the whole train set: + 32 per tile behind this slice (exact: integers < 2^24);
                 // "no neighbour" keys stay below 2^15 (at most 1023 tiles)
-                const float behind = 32.f * (float)(n_tiles - t_end);
+                const float behind = MM_TILE_AGE * (float)(n_tiles - t_end);
                 uint32_t* part = a.partial + ((size_t)pair * a.n_slices + blockIdx.y) * 2 * a.cap;
                 part[q] = __float_as_uint(__uint_as_float(m0) + behind);
                 part[a.cap + q] = __float_as_uint(__uint_as_float(m1) + behind);
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         {
             const size_t o = (size_t)pair * a.cap + q;
             const int last = 32 * n_tiles - 1;
-            const uint32_t k0 = (uint32_t)__uint_as_float(m0), k1 = (uint32_t)__uint_as_float(m1); // exact integers
+            const uint32_t k0 = mm_key_int(m0), k1 = mm_key_int(m1); // exact integers
             // key >> 15 = dot / 2 + 129 = 257 - hamming
             a.idx0[o] = (k0 >> 15) ? last - (int)(k0 & 32767u) : -1;
             a.idx1[o] = (k1 >> 15) ? last - (int)(k1 & 32767u) : -1;
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(256) void k_match_merge(MatchArgs a)
     }
     const size_t o = (size_t)pair * a.cap + q;
     const int last = 32 * n_tiles - 1;
-    const uint32_t k0 = (uint32_t)__uint_as_float(b0), k1 = (uint32_t)__uint_as_float(b1); // exact integers
+    const uint32_t k0 = mm_key_int(b0), k1 = mm_key_int(b1); // exact integers
     a.idx0[o] = (k0 >> 15) ? last - (int)(k0 & 32767u) : -1;
     a.idx1[o] = (k1 >> 15) ? last - (int)(k1 & 32767u) : -1;
     a.dist0[o] = (k0 >> 15) ? (int32_t)(257u - (k0 >> 15)) : INT_MAX;
@@ -782,7 +790,7 @@ __global__ __launch_bounds__(1024) void k_merge_ratio(MatchArgs a, RatioArgs r)
                     b1 = max(min(b0, k0), max(b1, k1));
                     b0 = max(b0, k0);
                 }
-                const uint32_t k0 = (uint32_t)__uint_as_float(b0), k1 = (uint32_t)__uint_as_float(b1); // exact integers
+                const uint32_t k0 = mm_key_int(b0), k1 = mm_key_int(b1); // exact integers
                 // key >> 15 = 257 - hamming; a key without a neighbour decodes to distance INT_MAX, which fails the test
                 fi = (k0 >> 15) ? last - (int)(k0 & 32767u) : -1;
                 const int d0 = (k0 >> 15) ? (int)(257u - (k0 >> 15)) : INT_MAX, d1 = (k1 >> 15) ? (int)(257u - (k1 >> 15)) : INT_MAX;
