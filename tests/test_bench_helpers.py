@@ -90,3 +90,39 @@ def test_profile_is_only_quoted_for_its_sources(tmp_path, monkeypatch):
     t, note = bench.pmc_traffic("gray", 1000)
     assert t is None and note.startswith("stale")
     assert bench.valu_issue_ms(None, 1000) is None
+
+
+def test_mempath_busy_fractions_and_their_gating(tmp_path, monkeypatch):
+    """tools/summarize_mempath.py on two (X, GRBM_GUI_ACTIVE) passes: TA busy = TA_TA_BUSY_sum / 256 CUs and vector issue =
+    SQ_INSTS_VALU x 4 / 1024 SIMDs, each over GRBM_GUI_ACTIVE / 8 XCDs of its own pass, summed over a stage's kernels and launches;
+    bench.busy_fracs quotes them only for the kernel sources they were collected on; the level chain's kernel maps to its stage"""
+    assert bench.stage_of_kernel("void mslam::k_level_chain<false, 8, true, 8, true>") == "levels"
+    hdr = "Kernel_Name,Counter_Name,Counter_Value\n"
+    ta = tmp_path / "ta.csv"
+    va = tmp_path / "va.csv"
+    rows_ta, rows_va = [], []
+    for launch in range(3):  # describe: TA busy 256 * 600 over GRBM 8 * 1000 -> 0.6; two resize kernels: (256*100 + 256*300) / (8*400 + 8*600) -> 0.4
+        rows_ta += ['"void mslam::k_describe<true>(x)",TA_TA_BUSY_sum,%d' % (256 * 600), '"void mslam::k_describe<true>(x)",GRBM_GUI_ACTIVE,%d' % (8 * 1000)]
+        rows_ta += ['"void mslam::k_resize_blur<false, 8, true, 0>(x)",TA_TA_BUSY_sum,%d' % (256 * 100), '"void mslam::k_resize_blur<false, 8, true, 0>(x)",GRBM_GUI_ACTIVE,%d' % (8 * 400)]
+        rows_ta += ['"void mslam::k_resize_blur<false, 0, true, 0>(x)",TA_TA_BUSY_sum,%d' % (256 * 300), '"void mslam::k_resize_blur<false, 0, true, 0>(x)",GRBM_GUI_ACTIVE,%d' % (8 * 600)]
+        rows_va += ['"void mslam::k_describe<true>(x)",SQ_INSTS_VALU,%d' % (1024 * 125), '"void mslam::k_describe<true>(x)",GRBM_GUI_ACTIVE,%d' % (8 * 1000)]
+    ta.write_text(hdr + "\n".join(rows_ta) + "\n")
+    va.write_text(hdr + "\n".join(rows_va) + "\n")
+    out = tmp_path / "mp.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_mempath.py"), str(out), str(ta), str(va)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(out.read_text())
+    d = j["kernels"]["mslam::k_describe<true>"]
+    assert abs(d["ta_busy_frac"] - 0.6) < 1e-12 and abs(d["valu_issue_frac"] - 0.5) < 1e-12 and d["ta_busy_frac_sums"]["launches"] == 3
+    monkeypatch.setattr(bench, "MEMPATH_PROFILE", str(out))
+    t, v, note = bench.busy_fracs("describe")
+    assert abs(t - 0.6) < 1e-12 and abs(v - 0.5) < 1e-12 and "GRBM_GUI_ACTIVE" in note
+    t, v, _ = bench.busy_fracs("resize")
+    assert abs(t - 0.4) < 1e-12 and v is None                            # both template instances, ratio of sums
+    j["_meta"]["csrc_sha"] = "0123456789abcdef"
+    out.write_text(json.dumps(j))
+    t, v, note = bench.busy_fracs("describe")
+    assert t is None and v is None and "stale" in note
+    monkeypatch.setattr(bench, "MEMPATH_PROFILE", str(tmp_path / "missing.json"))
+    assert bench.busy_fracs("describe")[0] is None
